@@ -1,0 +1,386 @@
+"""`backgammon_env` -- host-side mirror of the reference's pybind11 module of the same name
+(cppsrc/backgammon_bindings.cpp:41-94), running on MI355X through libbgamd.so.
+
+Same names, argument meaning and error behaviour as the reference module:
+    PlayerType, Player, Pieces, Game           (scalar surface: one board = a one-lane env)
+plus the vectorised surface the batched self-play loop uses:
+    VecGame                                    (n boards per device, one board per lane)
+and, in `backgammon_env.policy`, the TDLGammonModel operators (encode / forward / make_move).
+
+Everything that computes runs in HIP kernels; there is no CPU fallback.  PyTorch is used only
+to own device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import AUTO_RESET, BF16, F32, NO_FLIP, ROLL, BgamdError  # noqa: F401
+
+__all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed"]
+
+ERR_MESSAGES = {                                   # cppsrc/game.cpp:585-642, in source order
+    0: "", 1: "Invalid origin", 2: "Origin out of range", 3: "Destination out of range",
+    4: "Cannot move in that direction.", 5: "Move does not match dice.", 6: "Invalid destination.",
+    7: "Cannot bear off from jail",
+}
+
+_seed = int.from_bytes(os.urandom(8), "little")    # reference: random_device (game.hpp:45)
+_next_scalar_id = 0
+
+
+def set_seed(seed: int):
+    """Seeds the dice of scalar Game objects created afterwards (the reference cannot be seeded)."""
+    global _seed, _next_scalar_id
+    _seed = int(seed) & (2 ** 64 - 1)
+    _next_scalar_id = 0
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PlayerType(enum.IntEnum):                    # bindings.cpp:46-48 (unscoped enum: equals ints)
+    PLAYER1 = 0
+    PLAYER2 = 1
+
+
+PLAYER1, PLAYER2 = PlayerType.PLAYER1, PlayerType.PLAYER2
+
+
+class Player:                                      # bindings.cpp:51-54, cppsrc/player.hpp:6-27
+    def __init__(self, name: str, num: PlayerType):
+        if not isinstance(name, str) or not isinstance(num, PlayerType):
+            raise TypeError("Player(name: str, num: PlayerType)")
+        self._name, self._num = name, int(num)
+
+    def getName(self):
+        return self._name
+
+    def getNum(self):
+        return self._num
+
+
+class Pieces:                                      # bindings.cpp:57-59: live view of a Game's counters
+    def __init__(self, game: "Game"):
+        self._game = game
+
+    def numJailed(self, player):
+        return self._game.getJailedCount(player)
+
+    def numFreed(self, player):
+        return self._game.getBornOffCount(player)
+
+
+class VecGame:
+    """n concurrent games on one MI355X, one board per lane (include/bgamd.h)."""
+
+    def __init__(self, n_games: int, device: int = 0, seed: int = 20240603, lane_offset: int = 0,
+                 lane_stride: int | None = None, arena_rows: int = 0):
+        self._lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise BgamdError("no GPU visible: backgammon_env has no CPU fallback")
+        self.n = int(n_games)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        _capi.check(self._lib.bgamd_env_create(C.byref(h), self.n, device, seed, lane_offset,
+                                               lane_stride or 0, arena_rows), "bgamd_env_create")
+        self._h = h
+        self._has_weights = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bgamd_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _buf(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _dev(self, x, dtype, shape):
+        t = torch.as_tensor(x, dtype=dtype).to(self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            t = t.expand(shape).contiguous()
+        return t
+
+    # -- state
+    def reset(self):
+        _capi.check(self._lib.bgamd_env_reset(self._h, _stream()), "reset")
+
+    def set_states(self, states28=None, turn=None):
+        s = self._dev(states28, torch.int32, (self.n, 28)) if states28 is not None else None
+        t = self._dev(turn, torch.int32, (self.n,)) if turn is not None else None
+        _capi.check(self._lib.bgamd_env_set_states(self._h, _ptr(s), _ptr(t), _stream()), "set_states")
+        torch.cuda.current_stream().synchronize()     # s / t may be temporaries
+
+    def states(self):
+        s = self._buf((self.n, 28), torch.int32)
+        _capi.check(self._lib.bgamd_env_get_states(self._h, _ptr(s), None, _stream()), "get_states")
+        return s
+
+    def turns(self):
+        t = self._buf((self.n,), torch.int32)
+        _capi.check(self._lib.bgamd_env_get_states(self._h, None, _ptr(t), _stream()), "get_states")
+        return t
+
+    def flags(self):
+        f = self._buf((self.n,), torch.int32)
+        _capi.check(self._lib.bgamd_env_get_flags(self._h, _ptr(f), _stream()), "get_flags")
+        return f
+
+    def set_dice(self, dice):
+        d = self._dev(dice, torch.int32, (self.n, 2))
+        _capi.check(self._lib.bgamd_env_set_dice(self._h, _ptr(d), _stream()), "set_dice")
+        torch.cuda.current_stream().synchronize()
+
+    def dice(self):
+        d = self._buf((self.n, 2), torch.int32)
+        _capi.check(self._lib.bgamd_env_get_dice(self._h, _ptr(d), _stream()), "get_dice")
+        return d
+
+    def roll(self, advance_ply: bool = False):
+        _capi.check(self._lib.bgamd_env_roll(self._h, int(advance_ply), _stream()), "roll")
+
+    # -- enumeration (evaluateTurnSequences for every lane)
+    def enumerate(self, player=None, dice=None):
+        """-> (offsets int64[n], counts int32[n], states int32[N,28], seq int8[N,4,2], seq_len int32[N]),
+        rows of lane g = [offsets[g], offsets[g]+counts[g]), reference order."""
+        p = self._dev(player, torch.int32, (self.n,)) if player is not None else None
+        d = self._dev(dice, torch.int32, (self.n, 2)) if dice is not None else None
+        _capi.check(self._lib.bgamd_env_enumerate(self._h, _ptr(p), _ptr(d), _stream()), "enumerate")
+        offs, cnts = self._buf((self.n,), torch.int64), self._buf((self.n,), torch.int32)
+        total = _capi.check(self._lib.bgamd_env_candidates_info(self._h, _ptr(offs), _ptr(cnts), _stream()),
+                            "candidates_info")
+        st = self._buf((total, 28), torch.int32)
+        sq = self._buf((total, 4, 2), torch.int8)
+        ln = self._buf((total,), torch.int32)
+        _capi.check(self._lib.bgamd_env_candidates_read(self._h, 0, total, _ptr(st), _ptr(sq), _ptr(ln), _stream()),
+                    "candidates_read")
+        return offs, cnts, st, sq, ln
+
+    # -- the env step
+    def load_weights(self, weights):
+        """weights: flat float32[25601] = W1[128,198] | b1[128] | W2[128] | b2[1], or a state_dict with
+        fc1.weight / fc1.bias / fc2.weight / fc2.bias (the reference checkpoints, train.py:513-515)."""
+        if isinstance(weights, dict):
+            weights = np.concatenate([np.asarray(weights[k].detach().cpu().float()).ravel()
+                                      for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")])
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.float32).ravel())
+        if w.size != 25601:
+            raise ValueError("expected 25601 weights (198->128->1)")
+        _capi.check(self._lib.bgamd_env_load_weights(self._h, w.ctypes.data_as(C.c_void_p)), "load_weights")
+        self._has_weights = True
+
+    @staticmethod
+    def _flags(roll, auto_reset, no_flip=False):
+        return (ROLL if roll else 0) | (AUTO_RESET if auto_reset else 0) | (NO_FLIP if no_flip else 0)
+
+    def step_random(self, roll=True, auto_reset=True, choice_u32=None, no_flip=False):
+        c = None
+        if choice_u32 is not None:
+            c = torch.as_tensor(np.asarray(choice_u32, dtype=np.uint32).view(np.int32)).to(self.device).contiguous()
+        _capi.check(self._lib.bgamd_env_step_random(self._h, self._flags(roll, auto_reset, no_flip), _ptr(c), _stream()),
+                    "step_random")
+        if c is not None:
+            torch.cuda.current_stream().synchronize()
+
+    def step_greedy(self, roll=True, auto_reset=True, epsilon=0.0, precision=F32, no_flip=False):
+        _capi.check(self._lib.bgamd_env_step_greedy(self._h, self._flags(roll, auto_reset, no_flip), float(epsilon),
+                                                    int(precision), _stream()), "step_greedy")
+
+    def last_choice(self):
+        ch, cnt = self._buf((self.n,), torch.int32), self._buf((self.n,), torch.int32)
+        sq, ln = self._buf((self.n, 4, 2), torch.int8), self._buf((self.n,), torch.int32)
+        val = self._buf((self.n,), torch.float32)
+        _capi.check(self._lib.bgamd_env_last_choice(self._h, _ptr(ch), _ptr(cnt), _ptr(sq), _ptr(ln), _ptr(val), _stream()),
+                    "last_choice")
+        return {"chosen": ch, "count": cnt, "seq": sq, "seq_len": ln, "value": val}
+
+    def stats(self):
+        out = (C.c_uint64 * 6)()
+        _capi.check(self._lib.bgamd_env_stats(self._h, out), "stats")
+        k = ("steps", "games_finished", "p1_wins", "candidates_raw", "rows_evaluated", "error_flags")
+        return dict(zip(k, [int(v) for v in out]))
+
+    def reset_stats(self):
+        _capi.check(self._lib.bgamd_env_reset_stats(self._h, _stream()), "reset_stats")
+
+    # -- single-checker surface
+    def legal_moves(self, player, die):
+        p = self._dev(player, torch.int32, (self.n,))
+        d = self._dev(die, torch.int32, (self.n,))
+        n, pairs = self._buf((self.n,), torch.int32), self._buf((self.n, 26, 2), torch.int8)
+        _capi.check(self._lib.bgamd_env_legal_moves(self._h, _ptr(p), _ptr(d), _ptr(n), _ptr(pairs), _stream()), "legal_moves")
+        torch.cuda.current_stream().synchronize()
+        return n, pairs
+
+    def try_move(self, player, dice, origin, dest):
+        args = [self._dev(a, torch.int32, (self.n,)) for a in (player, dice, origin, dest)]
+        err = self._buf((self.n,), torch.int32)
+        _capi.check(self._lib.bgamd_env_try_move(self._h, *[_ptr(a) for a in args], _ptr(err), _stream()), "try_move")
+        torch.cuda.current_stream().synchronize()
+        return err
+
+    # -- stateless operators on caller-provided states
+    def encode(self, states28, turn):
+        st = torch.as_tensor(states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)
+        n = st.shape[0]
+        t = self._dev(turn, torch.int32, (n,))
+        out = self._buf((n, 198), torch.float32)
+        _capi.check(self._lib.bgamd_encode(_ptr(st), _ptr(t), n, _ptr(out), _stream()), "encode")
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def evaluate(self, states28, turn, precision=F32):
+        st = torch.as_tensor(states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)
+        n = st.shape[0]
+        t = self._dev(turn, torch.int32, (n,))
+        out = self._buf((n,), torch.float32)
+        _capi.check(self._lib.bgamd_evaluate(self._h, _ptr(st), _ptr(t), n, int(precision), _ptr(out), _stream()), "evaluate")
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    # -- kernel timing (bench.py)
+    def time_kernels(self, enable=True):
+        _capi.check(self._lib.bgamd_env_time_kernels(self._h, int(enable)), "time_kernels")
+
+    def kernel_times(self):
+        ms, n = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        _capi.check(self._lib.bgamd_env_kernel_times(self._h, ms, n), "kernel_times")
+        names = ("emit", "eval", "select_apply", "step_random")
+        return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
+
+
+class Game:
+    """The reference `Game` (bindings.cpp:62-93) on a one-lane device env."""
+
+    _ARENA = 32768          # > the largest doubles enumeration observed (10 063)
+
+    def __init__(self, player: int = 0):
+        global _next_scalar_id
+        self._v = VecGame(1, device=torch.cuda.current_device() if torch.cuda.is_available() else 0,
+                          seed=_seed, lane_offset=_next_scalar_id, lane_stride=1 << 40, arena_rows=self._ARENA)
+        _next_scalar_id += 1
+        self._players = [None, None]
+        self._v.set_states(None, [int(player) % 2])          # Game::Game(int): turn = parity (game.cpp:44-53)
+
+    # players ------------------------------------------------------------------------------
+    def setPlayers(self, p1: Player, p2: Player):
+        self._players = [p1, p2]                              # kept alive here (reference keeps raw pointers)
+
+    def getPlayers(self, num):
+        p = self._players[0 if int(num) == 0 else 1]
+        return Player(p.getName(), PlayerType(p.getNum()))    # by-value copy, as the binding returns
+
+    # turn / board ---------------------------------------------------------------------------
+    def getTurn(self):
+        return int(self._v.turns()[0])
+
+    def setTurn(self, turn):
+        self._v.set_states(None, [int(turn) & 1])
+
+    def _state(self):
+        return self._v.states()[0].cpu().tolist()
+
+    def getGameBoard(self):
+        return self._state()[:24]
+
+    def getPieces(self):
+        return Pieces(self)
+
+    def getJailedCount(self, player):
+        return self._state()[24 + (0 if int(player) == 0 else 1)]
+
+    def getBornOffCount(self, player):
+        return self._state()[26 + (0 if int(player) == 0 else 1)]
+
+    def setGameBoard(self, board):
+        board = [int(v) for v in board]
+        if len(board) != 24:
+            raise ValueError("gameboard must have 24 entries")
+        s = self._state()
+        self._v.set_states([board + s[24:]], None)
+
+    def setBorneOffPieces(self, player, num):
+        s = self._state()
+        s[26 + (0 if int(player) == 0 else 1)] = int(num)
+        self._v.set_states([s], None)
+
+    def _set_jailed(self, player, num):
+        """Not in the reference binding (bar counts are only reachable by hits); used by tests/clone."""
+        s = self._state()
+        s[24 + (0 if int(player) == 0 else 1)] = int(num)
+        self._v.set_states([s], None)
+
+    def reset(self):
+        self.populateBoard()                                   # binding maps reset -> populateBoard only
+
+    def populateBoard(self):
+        s = self._state()
+        self._v.set_states([[2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2] + s[24:]], None)
+
+    def printGameBoard(self):
+        s = self._state()
+        print("board", s[:24], "| jail", s[24:26], "| free", s[26:28])
+
+    # dice -------------------------------------------------------------------------------------
+    def setDice(self, d1, d2):
+        self._v.set_dice([[int(d1), int(d2)]])
+
+    def roll_dice(self):
+        self._v.roll(advance_ply=True)
+        return self.get_last_dice()
+
+    def get_last_dice(self):
+        d = self._v.dice()[0].cpu().tolist()
+        return d if d[0] else [1, 1]
+
+    # rules --------------------------------------------------------------------------------------
+    def legalMoves(self, player, die):
+        n, pairs = self._v.legal_moves([int(player)], [int(die)])
+        k = int(n[0])
+        return [(int(a), int(b)) for a, b in pairs[0, :k].cpu().tolist()]
+
+    def _enumerate(self, player, d1, d2):
+        _, cnts, st, sq, ln = self._v.enumerate([int(player)], [[int(d1), int(d2)]])
+        k = int(cnts[0])
+        sq, ln = sq[:k].cpu().numpy(), ln[:k].cpu().numpy()
+        seqs = [[(int(sq[i, j, 0]), int(sq[i, j, 1])) for j in range(ln[i])] for i in range(k)]
+        return seqs, st[:k]
+
+    def legalTurnSequences(self, player, die1, die2):
+        return self._enumerate(player, die1, die2)[0]
+
+    def evaluateTurnSequences(self, player, die1, die2):
+        seqs, st = self._enumerate(player, die1, die2)
+        return seqs, st.cpu().numpy().astype(np.int32).reshape(-1, 28)
+
+    def tryMove(self, player: Player, dice, origin, dest):
+        err = int(self._v.try_move([player.getNum()], [int(dice)], [int(origin)], [int(dest)])[0])
+        return err == 0, ERR_MESSAGES[err]
+
+    def is_game_over(self):
+        f = int(self._v.flags()[0])
+        return (True, (f >> 1) & 1) if f & 1 else (False, -1)
+
+    def clone(self):
+        g = Game(0)
+        g._players = list(self._players)
+        g._v.set_states([self._state()], [self.getTurn()])     # last_dice stays [1,1] (game.cpp:68-77)
+        return g

@@ -1,0 +1,86 @@
+"""ctypes binding of libbgamd.so (include/bgamd.h).
+
+There is NO CPU fallback: importing this module without the built HIP library, or creating an
+env without a gfx950 device, raises.  The library is built in-tree by
+`__graft_entry__.build()` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbgamd.so")
+
+OK = 0
+ROLL, AUTO_RESET, NO_FLIP = 1, 2, 4
+F32, BF16 = 0, 1
+
+# every symbol include/bgamd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("bgamd_version", C.c_int, []),
+    ("bgamd_error_string", C.c_char_p, [C.c_int]),
+    ("bgamd_last_hip_error", C.c_char_p, []),
+    ("bgamd_device_count", C.c_int, []),
+    ("bgamd_env_create", C.c_int, [C.POINTER(_P), C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]),
+    ("bgamd_env_destroy", C.c_int, [_P]),
+    ("bgamd_env_num_games", C.c_int64, [_P]),
+    ("bgamd_env_reset", C.c_int, [_P, _P]),
+    ("bgamd_env_set_states", C.c_int, [_P, _P, _P, _P]),
+    ("bgamd_env_get_states", C.c_int, [_P, _P, _P, _P]),
+    ("bgamd_env_get_flags", C.c_int, [_P, _P, _P]),
+    ("bgamd_env_set_dice", C.c_int, [_P, _P, _P]),
+    ("bgamd_env_get_dice", C.c_int, [_P, _P, _P]),
+    ("bgamd_env_roll", C.c_int, [_P, C.c_int, _P]),
+    ("bgamd_env_enumerate", C.c_int, [_P, _P, _P, _P]),
+    ("bgamd_env_candidates_info", C.c_int64, [_P, _P, _P, _P]),
+    ("bgamd_env_candidates_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    ("bgamd_env_step_random", C.c_int, [_P, C.c_int, _P, _P]),
+    ("bgamd_env_load_weights", C.c_int, [_P, _P]),
+    ("bgamd_env_step_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, _P]),
+    ("bgamd_env_last_choice", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("bgamd_env_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("bgamd_env_reset_stats", C.c_int, [_P, _P]),
+    ("bgamd_env_try_move", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("bgamd_env_legal_moves", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("bgamd_encode", C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    ("bgamd_evaluate", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("bgamd_env_time_kernels", C.c_int, [_P, C.c_int]),
+    ("bgamd_env_kernel_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+]
+
+
+class BgamdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libbgamd.so and type every entry point.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BgamdError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc >= 0:
+        return rc
+    lib = load()
+    msg = lib.bgamd_error_string(int(rc)).decode()
+    if rc == -2:
+        msg += ": " + lib.bgamd_last_hip_error().decode()
+    raise BgamdError(f"{what or 'bgamd'} failed ({rc}): {msg}")

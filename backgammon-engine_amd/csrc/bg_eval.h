@@ -1,0 +1,199 @@
+// bg_eval.h -- 198-feature encoder + 198->128->1 sigmoid value net over packed candidate rows.
+//
+// Restates TDLGammonModel._encode_states_np (pysrc/TD(λ) model/model.py:111-144) and
+// TDLGammonModel.forward (model.py:63-67).  The 198 features are never materialised: each
+// MFMA A-operand element is decoded from the row's bit planes right before it is consumed.
+//
+// fp32 kernel: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, K = 198 = 99 steps of 2).
+//   A[row][k]  : lane l supplies row (l & 31), feature k = 2*s + (l >> 5)
+//   B[k][n]    : W1[n][k]; lane l supplies n = 32*c + (l & 31), k = 2*s + (l >> 5) for the four
+//                32-column tiles c -- staged ONCE per workgroup in LDS as float4[99][64]
+//   D[row][n]  : 4 tiles x 16 accumulators; row = (reg&3) + 8*(reg>>2) + 4*(l>>5), n = 32*c + (l&31)
+// Epilogue fused: + b1, sigmoid, dot with W2 over the 128 hidden units (4 per lane, then a
+// 32-lane butterfly), + b2, sigmoid -> one fp32 value per row.
+#pragma once
+#include "bg_board.h"
+
+namespace bg {
+
+constexpr int N_IN = 198, N_HID = 128;
+constexpr int N_PARAMS = N_HID * N_IN + N_HID + N_HID + 1;
+constexpr int K_STEPS = N_IN / 2;                  // 99
+constexpr int EVAL_LDS_BYTES = K_STEPS * 64 * 16;  // 101 376
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    // 1 / (1 + 2^(-x*log2 e)); v_exp_f32 + v_rcp_f32, |err| ~ 2e-7 absolute on (0,1)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+
+// per-row decode state: for each side q (0 = PLAYER1, 1 = PLAYER2)
+//   ev[q]   : mask whose bit (i+1) is this lane's EVEN-step feature of point i  (n>=1 | n>=2)
+//   od[q][k]: planes of the odd-step code; feature value = 0.5 * code            (n>=3 | (n-3)/2)
+struct RowDecode {
+    uint32_t ev[2];
+    uint32_t od[2][4];
+    float tail[3];
+};
+
+__device__ __forceinline__ void decode_setup(const uint32_t (&p)[8], int h, RowDecode &r)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t b0 = p[4 * q] & PTS, b1 = p[4 * q + 1] & PTS, b2 = p[4 * q + 2] & PTS, b3 = p[4 * q + 3] & PTS;
+        const uint32_t ge1 = b0 | b1 | b2 | b3;
+        const uint32_t ge2 = b1 | b2 | b3;
+        const uint32_t ge3 = (b0 & b1) | b2 | b3;
+        const uint32_t ge4 = b2 | b3;
+        // bit-sliced (n + 13) mod 16 == n - 3 for n >= 3, masked to n >= 4
+        const uint32_t s0 = ~b0, c0 = b0;
+        const uint32_t s1 = b1 ^ c0, c1 = b1 & c0;
+        const uint32_t s2 = ~(b2 ^ c1), c2 = b2 | c1;
+        const uint32_t s3 = ~(b3 ^ c2);
+        r.ev[q] = h ? ge2 : ge1;
+        r.od[q][0] = h ? (s0 & ge4) : 0u;
+        r.od[q][1] = h ? (s1 & ge4) : ge3;          // code 2 -> 1.0 for the n>=3 flag
+        r.od[q][2] = h ? (s2 & ge4) : 0u;
+        r.od[q][3] = h ? (s3 & ge4) : 0u;
+    }
+    const Side a{{p[0], p[1], p[2], p[3]}}, b{{p[4], p[5], p[6], p[7]}};
+    const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+    r.tail[0] = (h == turn) ? 1.0f : 0.0f;                               // 192 / 193
+    r.tail[1] = 0.5f * (float)(h ? count_at(b, 25) : count_at(a, 0));    // 194 / 195: bar / 2
+    r.tail[2] = (float)(h ? count_at(b, 0) : count_at(a, 25)) / 15.0f;   // 196 / 197: off / 15
+}
+
+__device__ __forceinline__ float decode_even(const RowDecode &r, int q, int i)
+{
+    return (float)((r.ev[q] >> (i + 1)) & 1u);
+}
+__device__ __forceinline__ float decode_odd(const RowDecode &r, int q, int i)
+{
+    const int sh = i + 1;
+    const uint32_t code = ((r.od[q][0] >> sh) & 1u) | (((r.od[q][1] >> sh) & 1u) << 1) |
+                          (((r.od[q][2] >> sh) & 1u) << 2) | (((r.od[q][3] >> sh) & 1u) << 3);
+    return 0.5f * (float)code;
+}
+
+// Host-side weight re-layout for the fp32 kernel: Wl[s][l][c] = W1[32c + (l&31)][2s + (l>>5)]
+inline void relayout_w1_f32(const float *w1 /*[128][198]*/, float *wl /*[99][64][4]*/)
+{
+    for (int s = 0; s < K_STEPS; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int c = 0; c < 4; ++c)
+                wl[(s * 64 + l) * 4 + c] = w1[(32 * c + (l & 31)) * N_IN + 2 * s + (l >> 5)];
+}
+
+// rows: 2 x uint4 per candidate.  n_rows_ptr: device counter (rows emitted this step), or null -> n_rows_imm.
+__global__ __launch_bounds__(256) void eval_rows_f32_kernel(
+    const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
+    unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wl, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2p, float *__restrict__ values)
+{
+    extern __shared__ float4 sW[];
+    for (int i = threadIdx.x; i < K_STEPS * 64; i += 256) sW[i] = wl[i];
+    __syncthreads();
+
+    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
+    const long long n_tiles = (n_rows + 31) >> 5;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+
+    float b1v[4], w2v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { b1v[c] = b1[32 * c + r]; w2v[c] = w2[32 * c + r]; }
+    const float b2 = *b2p;
+
+    for (long long tile = wave; tile < n_tiles; tile += n_waves) {
+        const long long row = tile * 32 + r;
+        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < n_rows) {
+            const uint4 u0 = rows[2 * row], u1 = rows[2 * row + 1];
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w;
+            p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+        RowDecode rd;
+        decode_setup(p, h, rd);
+
+        floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+#define BG_MFMA4(aval, s)                                                            \
+    {                                                                                \
+        const float4 w = sW[(s) * 64 + lane];                                        \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.x, acc0, 0, 0, 0);      \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.y, acc1, 0, 0, 0);      \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.z, acc2, 0, 0, 0);      \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.w, acc3, 0, 0, 0);      \
+    }
+#pragma unroll 2
+        for (int i = 0; i < 24; ++i) {
+            const float a0 = decode_even(rd, 0, i);
+            const float a1 = decode_odd(rd, 0, i);
+            const float a2 = decode_even(rd, 1, i);
+            const float a3 = decode_odd(rd, 1, i);
+            BG_MFMA4(a0, 4 * i);
+            BG_MFMA4(a1, 4 * i + 1);
+            BG_MFMA4(a2, 4 * i + 2);
+            BG_MFMA4(a3, 4 * i + 3);
+        }
+        BG_MFMA4(rd.tail[0], 96);
+        BG_MFMA4(rd.tail[1], 97);
+        BG_MFMA4(rd.tail[2], 98);
+#undef BG_MFMA4
+
+        // epilogue: hidden sigmoid, dot with W2 (this lane's 4 columns), 32-lane butterfly
+        float part[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            part[j] = w2v[0] * fast_sigmoid(acc0[j] + b1v[0]) + w2v[1] * fast_sigmoid(acc1[j] + b1v[1]) +
+                      w2v[2] * fast_sigmoid(acc2[j] + b1v[2]) + w2v[3] * fast_sigmoid(acc3[j] + b1v[3]);
+        }
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) part[j] += __shfl_xor(part[j], m, 64);
+        }
+        // lane (l & 31) == j < 16 stores accumulator register j of its half
+        float mine = part[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mine = (r == j) ? part[j] : mine;
+        if (r < 16) {
+            const long long orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < n_rows) values[orow] = fast_sigmoid(mine + b2);
+        }
+    }
+}
+
+// Stand-alone encoder (the reference's _encode_states_np surface): rows -> float[n][198]
+__global__ void encode_rows_kernel(const uint4 *__restrict__ rows, long long n, float *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint4 u0 = rows[2 * row], u1 = rows[2 * row + 1];
+    const uint32_t p[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
+    float *x = out + row * N_IN;
+    for (int i = 0; i < 24; ++i) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = count_at(sd[q], i + 1);
+            x[8 * i + 4 * q + 0] = c >= 1 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 1] = c >= 2 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 2] = c >= 3 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 3] = c >= 4 ? 0.5f * (float)(c - 3) : 0.0f;
+        }
+    }
+    const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+    x[192] = turn == 0 ? 1.0f : 0.0f;
+    x[193] = turn == 0 ? 0.0f : 1.0f;
+    x[194] = 0.5f * (float)count_at(sd[0], 0);
+    x[195] = 0.5f * (float)count_at(sd[1], 25);
+    x[196] = (float)count_at(sd[0], 25) / 15.0f;
+    x[197] = (float)count_at(sd[1], 0) / 15.0f;
+}
+
+}  // namespace bg

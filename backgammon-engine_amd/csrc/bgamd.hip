@@ -1,0 +1,972 @@
+// bgamd.hip -- kernels of the env step + the C ABI declared in include/bgamd.h (gfx950 only).
+//
+// Data layout in HBM (one env = n_games lanes on one device):
+//   planes   uint32[8][n]   bit-plane boards, SoA: a 64-lane wave reads 256 contiguous bytes per plane
+//   meta     uint32[n]      bit0 turn | bits4-6 die1 | bits8-10 die2 | bit12 finished
+//   ply, episode uint32[n]  Philox counter words (game_id = lane_offset + lane + episode*lane_stride)
+//   arena    uint4[2*cap]   candidate afterstates, 32 B rows, reference order inside a lane's segment
+//   values   float[cap]     value-net output per row
+// The step is: emit (count pass, wave-level bump allocation, emit pass) -> eval (MFMA) -> select/apply.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bgamd.h"
+#include "bg_board.h"
+#include "bg_eval.h"
+#include "bg_movegen.h"
+
+using namespace bg;
+
+namespace {
+
+enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_SCRATCH, C_COUNT };
+enum { ERRF_ARENA = 1, ERRF_STATE = 2 };
+constexpr uint32_t META_FINISHED = 1u << 12;
+
+struct EnvView {
+    long long n;
+    unsigned long long seed, lane_offset, lane_stride;
+    long long cap;
+    uint32_t *planes, *meta, *ply, *episode, *flags;
+    uint32_t *cand_off, *cand_cnt;
+    int32_t *chosen;
+    uint32_t *chosen_seq;
+    float *chosen_val;
+    uint4 *rows;
+    uint32_t *seqs;
+    float *values;
+    unsigned long long *counters;
+};
+
+__device__ __forceinline__ uint32_t meta_pack(int turn, int d1, int d2, bool fin)
+{
+    return (uint32_t)turn | ((uint32_t)d1 << 4) | ((uint32_t)d2 << 8) | (fin ? META_FINISHED : 0u);
+}
+
+__device__ __forceinline__ void load_planes(const EnvView &e, long long g, uint32_t (&p)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = e.planes[(long long)k * e.n + g];
+}
+__device__ __forceinline__ void store_planes(const EnvView &e, long long g, const uint32_t (&p)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e.planes[(long long)k * e.n + g] = p[k];
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v)
+{
+    unsigned long long s = v;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)s, m, 64), hi = __shfl_xor((uint32_t)(s >> 32), m, 64);
+        s += ((unsigned long long)hi << 32) | lo;
+    }
+    return s;
+}
+
+// Terminal check (game.cpp:388-407), auto-reset / turn flip (train.py:113-120), write-back.
+__device__ __forceinline__ void finish_turn(const EnvView &e, long long g, uint32_t (&p)[8], int turn, int d1, int d2,
+                                            uint32_t ply, uint32_t epi, int flags, bool live)
+{
+    uint32_t oflags = 0;
+    bool fin = false;
+    const int oc = live ? over_code(p) : 0;
+    if (oc) {
+        oflags = 1u | ((uint32_t)(oc - 1) << 1);
+        if (flags & BGAMD_AUTO_RESET) {
+            epi += 1; ply = 0;
+            constexpr StartPlanes sp = start_planes();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = sp.p[k];
+            const unsigned long long gid = e.lane_offset + (unsigned long long)g + (unsigned long long)epi * e.lane_stride;
+            turn = opening_turn(e.seed, gid);
+        } else if (!(flags & BGAMD_NO_FLIP)) {
+            fin = true; oflags |= 4u;
+        }
+    } else if (live && !(flags & BGAMD_NO_FLIP)) {
+        turn ^= 1; ply += 1;
+    }
+    if (live) {
+        store_planes(e, g, p);
+        e.meta[g] = meta_pack(turn, d1, d2, fin);
+        e.ply[g] = ply; e.episode[g] = epi; e.flags[g] = oflags;
+    }
+    const unsigned long long nsteps = wave_sum_u32(live ? 1u : 0u);
+    const unsigned long long nfin = wave_sum_u32(oc ? 1u : 0u);
+    const unsigned long long nw1 = wave_sum_u32(oc == 1 ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0) {
+        if (nsteps) atomicAdd(&e.counters[C_STEPS], nsteps);
+        if (nfin) atomicAdd(&e.counters[C_FINISHED], nfin);
+        if (nw1) atomicAdd(&e.counters[C_P1WINS], nw1);
+    }
+}
+
+struct LaneCtx {
+    uint32_t p[8];
+    uint32_t meta, ply, epi;
+    int turn, d1, d2;
+    U4 x;
+    bool live;
+};
+
+__device__ __forceinline__ void lane_begin(const EnvView &e, long long g, int flags, LaneCtx &c)
+{
+    c.live = g < e.n;
+    const long long gg = c.live ? g : 0;
+    load_planes(e, gg, c.p);
+    c.meta = e.meta[gg]; c.ply = e.ply[gg]; c.epi = e.episode[gg];
+    if (c.meta & META_FINISHED) c.live = false;
+    c.turn = c.meta & 1;
+    const unsigned long long gid = e.lane_offset + (unsigned long long)gg + (unsigned long long)c.epi * e.lane_stride;
+    c.x = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), c.ply, STREAM_TURN, (uint32_t)e.seed, (uint32_t)(e.seed >> 32));
+    if (flags & BGAMD_ROLL) { c.d1 = die_from_u32(c.x.x); c.d2 = die_from_u32(c.x.y); }
+    else { c.d1 = (c.meta >> 4) & 7; c.d2 = (c.meta >> 8) & 7; }
+    if (c.d1 < 1 || c.d1 > 6 || c.d2 < 1 || c.d2 > 6) { c.d1 = 1; c.d2 = 1; }   // Game::last_dice default {1,1}
+}
+
+__device__ __forceinline__ void split_sides(const uint32_t (&p)[8], int turn, Side &own, Side &opp)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        own.b[k] = turn ? p[4 + k] : p[k];
+        opp.b[k] = turn ? p[k] : p[4 + k];
+    }
+}
+__device__ __forceinline__ void join_sides(const Side &own, const Side &opp, int turn, uint32_t (&p)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k] = turn ? opp.b[k] : own.b[k];
+        p[4 + k] = turn ? own.b[k] : opp.b[k];
+    }
+}
+
+// ---- random-policy step: everything in one kernel ----------------------------------------------
+__global__ __launch_bounds__(64) void step_random_kernel(EnvView e, int flags, const uint32_t *__restrict__ choice)
+{
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    LaneCtx c;
+    lane_begin(e, g, flags, c);
+    Side own, opp;
+    split_sides(c.p, c.turn, own, opp);
+    uint32_t C = 0;
+    if (c.live) {
+        CountVisitor cv;
+        walk_sequences(own, opp, c.turn, c.d1, c.d2, cv);
+        C = cv.n;
+    }
+    int32_t chosen = -1;
+    uint32_t cseq = 0;
+    if (C > 0) {
+        const uint32_t u = choice ? choice[g] : c.x.z;
+        const uint32_t k = (uint32_t)(((unsigned long long)u * C) >> 32);
+        SelectVisitor sv(k);
+        walk_sequences(own, opp, c.turn, c.d1, c.d2, sv);
+        join_sides(sv.own, sv.opp, c.turn, c.p);
+        chosen = (int32_t)k; cseq = sv.seq;
+    }
+    if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.cand_cnt[g] = C; e.chosen_val[g] = 0.0f; }
+    const unsigned long long tot = wave_sum_u32(C);
+    if (threadIdx.x == 0 && tot) atomicAdd(&e.counters[C_CAND_RAW], tot);
+    finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
+}
+
+// ---- emit: count pass, wave-level bump allocation, emit pass ---------------------------------
+__global__ __launch_bounds__(64) void emit_kernel(EnvView e, int flags, int with_seq, const int32_t *__restrict__ ov_player,
+                                                  const int32_t *__restrict__ ov_dice)
+{
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    LaneCtx c;
+    lane_begin(e, g, flags, c);
+    if (g < e.n) {       // explicit (player, d1, d2) of legalTurnSequences / evaluateTurnSequences
+        if (ov_player) c.turn = ov_player[g] == 1 ? 1 : 0;
+        if (ov_dice) {
+            const int a = ov_dice[2 * g], b = ov_dice[2 * g + 1];
+            if (a >= 1 && a <= 6 && b >= 1 && b <= 6) { c.d1 = a; c.d2 = b; } else c.live = false;
+        }
+    }
+    Side own, opp;
+    split_sides(c.p, c.turn, own, opp);
+    uint32_t C = 0;
+    if (c.live) {
+        CountVisitor cv;
+        walk_sequences(own, opp, c.turn, c.d1, c.d2, cv);
+        C = cv.n;
+    }
+    // inclusive scan over the wave
+    uint32_t incl = C;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 0 && total) {
+        base = atomicAdd(&e.counters[C_ARENA_TOP], (unsigned long long)total);
+        atomicAdd(&e.counters[C_CAND_RAW], (unsigned long long)total);
+    }
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+    const bool overflow = base + total > (unsigned long long)e.cap;
+    if (overflow) {
+        if (lane == 0) atomicOr(&e.counters[C_ERR], (unsigned long long)ERRF_ARENA);
+        C = 0;
+    }
+    const unsigned long long my_off = overflow ? 0ull : base + incl - C;
+    if (C > 0) {
+        EmitVisitor ev(e.rows + 2 * my_off, with_seq ? e.seqs + my_off : nullptr, c.turn);
+        walk_sequences(own, opp, c.turn, c.d1, c.d2, ev);
+    }
+    if (g < e.n) {
+        e.cand_off[g] = (uint32_t)my_off;
+        e.cand_cnt[g] = C;
+        if ((flags & BGAMD_ROLL) && c.live) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
+    }
+}
+
+// ---- select + apply: argmax / argmin over each lane's segment, cooperative over the wave -------
+__global__ __launch_bounds__(64) void select_apply_kernel(EnvView e, int flags, float epsilon, int have_seq)
+{
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    LaneCtx c;
+    lane_begin(e, g, flags & ~BGAMD_ROLL, c);      // dice were stored by emit_kernel
+    const uint32_t cnt = (g < e.n && c.live) ? e.cand_cnt[g] : 0u;
+    const uint32_t off = (g < e.n) ? e.cand_off[g] : 0u;
+    unsigned long long mykey = 0;
+    for (int j = 0; j < 64; ++j) {
+        const uint32_t cj = __shfl(cnt, j, 64);
+        if (cj == 0) continue;
+        const uint32_t oj = __shfl(off, j, 64);
+        const int tj = __shfl(c.turn, j, 64);
+        unsigned long long best = 0;
+        for (uint32_t i = lane; i < cj; i += 64) {
+            uint32_t bits = __float_as_uint(e.values[(unsigned long long)oj + i]);
+            bits = tj ? ~bits : bits;                   // P2 minimises (model.py:212-213)
+            const unsigned long long key = ((unsigned long long)bits << 32) | (uint32_t)~i;   // first index wins ties
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)best, m, 64), hi = __shfl_xor((uint32_t)(best >> 32), m, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o > best ? o : best;
+        }
+        if (lane == j) mykey = best;
+    }
+    int32_t chosen = -1;
+    uint32_t cseq = 0;
+    float cval = 0.0f;
+    if (cnt > 0) {
+        uint32_t idx = ~(uint32_t)mykey;
+        if (epsilon > 0.0f && (float)(c.x.w >> 8) * (1.0f / 16777216.0f) < epsilon)
+            idx = (uint32_t)(((unsigned long long)c.x.z * cnt) >> 32);      // explore (model.py:205-206)
+        const unsigned long long r = (unsigned long long)off + idx;
+        const uint4 u0 = e.rows[2 * r], u1 = e.rows[2 * r + 1];
+        c.p[0] = u0.x & ~TURN_BIT; c.p[1] = u0.y; c.p[2] = u0.z; c.p[3] = u0.w;
+        c.p[4] = u1.x; c.p[5] = u1.y; c.p[6] = u1.z; c.p[7] = u1.w;
+        chosen = (int32_t)idx;
+        cval = e.values[r];
+        if (have_seq) cseq = e.seqs[r];
+    }
+    if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.chosen_val[g] = cval; }
+    finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
+}
+
+// ---- small state kernels ---------------------------------------------------------------------------
+__global__ void reset_kernel(EnvView e)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    constexpr StartPlanes sp = start_planes();
+    uint32_t p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = sp.p[k];
+    store_planes(e, g, p);
+    const unsigned long long gid = e.lane_offset + (unsigned long long)g;
+    e.meta[g] = meta_pack(opening_turn(e.seed, gid), 1, 1, false);
+    e.ply[g] = 0; e.episode[g] = 0; e.flags[g] = 0;
+    e.cand_off[g] = 0; e.cand_cnt[g] = 0; e.chosen[g] = -1; e.chosen_seq[g] = 0; e.chosen_val[g] = 0.0f;
+}
+
+__global__ void set_states_kernel(EnvView e, const int32_t *__restrict__ st, const int32_t *__restrict__ turn)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    if (st) {
+        uint32_t p[8];
+        int bad = 0;
+        int32_t s[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) s[i] = st[g * 28 + i];
+        planes_from_state28(s, p, &bad);
+        if (bad) atomicOr(&e.counters[C_ERR], (unsigned long long)ERRF_STATE);
+        store_planes(e, g, p);
+    }
+    const uint32_t m = e.meta[g];
+    const int t = turn ? (turn[g] & 1) : (int)(m & 1);
+    e.meta[g] = (m & ~(1u | META_FINISHED)) | (uint32_t)t;
+}
+
+__global__ void get_states_kernel(EnvView e, int32_t *__restrict__ st, int32_t *__restrict__ turn)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t p[8];
+    load_planes(e, g, p);
+    if (st) {
+        int32_t s[28];
+        state28_from_planes(p, s);
+#pragma unroll
+        for (int i = 0; i < 28; ++i) st[g * 28 + i] = s[i];
+    }
+    if (turn) turn[g] = (int32_t)(e.meta[g] & 1);
+}
+
+__global__ void get_flags_kernel(EnvView e, int32_t *__restrict__ out)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t p[8];
+    load_planes(e, g, p);
+    const int oc = over_code(p);          // is_game_over on the CURRENT board (game.cpp:388-407)
+    out[g] = (oc ? (1 | ((oc - 1) << 1)) : 0) | ((e.meta[g] & META_FINISHED) ? 4 : 0) | (int32_t)((e.flags[g] & 3u) << 4);
+}
+
+__global__ void dice_kernel(EnvView e, const int32_t *__restrict__ in, int32_t *__restrict__ out, int roll)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t m = e.meta[g];
+    if (in || roll) {
+        int d1, d2;
+        if (roll) {
+            const unsigned long long gid = e.lane_offset + (unsigned long long)g + (unsigned long long)e.episode[g] * e.lane_stride;
+            const U4 x = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), e.ply[g], STREAM_TURN, (uint32_t)e.seed, (uint32_t)(e.seed >> 32));
+            d1 = die_from_u32(x.x); d2 = die_from_u32(x.y);
+            if (roll == 2) e.ply[g] += 1;      // scalar Game::rollDice: every call draws fresh dice
+        } else { d1 = in[2 * g] & 7; d2 = in[2 * g + 1] & 7; }
+        m = (m & ~0x770u) | ((uint32_t)d1 << 4) | ((uint32_t)d2 << 8);
+        e.meta[g] = m;
+    }
+    if (out) { out[2 * g] = (m >> 4) & 7; out[2 * g + 1] = (m >> 8) & 7; }
+}
+
+__global__ void cand_info_kernel(EnvView e, int64_t *__restrict__ offs, int32_t *__restrict__ cnts)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    if (offs) offs[g] = (int64_t)e.cand_off[g];
+    if (cnts) cnts[g] = (int32_t)e.cand_cnt[g];
+}
+
+__device__ __forceinline__ void unpack_seq(uint32_t q, int8_t *out8, int32_t *len_out)
+{
+    const int len = (q >> 20) & 7, dA = (q >> 23) & 7, dB = (q >> 26) & 7;
+    // direction is recovered from the move itself: the mover's sign is not stored, so the
+    // caller passes it through bit 29 (1 = PLAYER2 moves down)
+    const int down = (q >> 29) & 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int o = -1, d = -1;
+        if (k < len) {
+            o = (q >> (5 * k)) & 31;
+            const int die = (k & 1) ? dB : dA;
+            d = down ? o - die : o + die;
+            d = d < 0 ? 0 : (d > 25 ? 25 : d);
+        }
+        out8[2 * k] = (int8_t)o; out8[2 * k + 1] = (int8_t)d;
+    }
+    if (len_out) *len_out = len;
+}
+
+__global__ void rows_read_kernel(const uint4 *__restrict__ rows, const uint32_t *__restrict__ seqs, long long first,
+                                 long long n, int32_t *__restrict__ st, int8_t *__restrict__ seq, int32_t *__restrict__ len)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = first + i;
+    const uint4 u0 = rows[2 * r], u1 = rows[2 * r + 1];
+    const uint32_t p[8] = {u0.x & ~TURN_BIT, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    if (st) {
+        int32_t s[28];
+        state28_from_planes(p, s);
+#pragma unroll
+        for (int k = 0; k < 28; ++k) st[i * 28 + k] = s[k];
+    }
+    if (seq) {
+        const uint32_t q = seqs[r] | ((u0.x & TURN_BIT) ? (1u << 29) : 0u);
+        unpack_seq(q, seq + i * 8, len ? len + i : nullptr);
+    }
+}
+
+__global__ void last_choice_kernel(EnvView e, int32_t *chosen, int32_t *count, int8_t *seq, int32_t *len, float *val)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    if (chosen) chosen[g] = e.chosen[g];
+    if (count) count[g] = (int32_t)e.cand_cnt[g];
+    if (val) val[g] = e.chosen_val[g];
+    if (seq) {
+        // the mover of the last step: turn was flipped unless the game ended / NO_FLIP; the packed
+        // sequence carries the direction in bit 29, set by the step kernels' callers below
+        unpack_seq(e.chosen_seq[g], seq + g * 8, len ? len + g : nullptr);
+    }
+}
+
+__global__ void pack_rows_kernel(const int32_t *__restrict__ st, const int32_t *__restrict__ turn, long long n,
+                                 uint4 *__restrict__ rows, unsigned long long *err)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t s[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s[k] = st[i * 28 + k];
+    uint32_t p[8];
+    int bad = 0;
+    planes_from_state28(s, p, &bad);
+    if (bad && err) atomicOr(err, (unsigned long long)ERRF_STATE);
+    const int t = turn ? (turn[i] & 1) : 0;
+    rows[2 * i] = make_uint4(p[0] | (t ? TURN_BIT : 0u), p[1], p[2], p[3]);
+    rows[2 * i + 1] = make_uint4(p[4], p[5], p[6], p[7]);
+}
+
+__global__ void encode_states_kernel(const int32_t *__restrict__ st, const int32_t *__restrict__ turn, long long n,
+                                     float *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    int32_t s[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s[k] = st[row * 28 + k];
+    uint32_t p[8];
+    planes_from_state28(s, p, nullptr);
+    const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
+    float *x = out + row * N_IN;
+    for (int i = 0; i < 24; ++i) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = count_at(sd[q], i + 1);
+            x[8 * i + 4 * q + 0] = c >= 1 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 1] = c >= 2 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 2] = c >= 3 ? 1.0f : 0.0f;
+            x[8 * i + 4 * q + 3] = c >= 4 ? 0.5f * (float)(c - 3) : 0.0f;
+        }
+    }
+    const int t = turn ? (turn[row] & 1) : 0;
+    x[192] = t == 0 ? 1.0f : 0.0f;
+    x[193] = t == 0 ? 0.0f : 1.0f;
+    x[194] = 0.5f * (float)count_at(sd[0], 0);
+    x[195] = 0.5f * (float)count_at(sd[1], 25);
+    x[196] = (float)count_at(sd[0], 25) / 15.0f;
+    x[197] = (float)count_at(sd[1], 0) / 15.0f;
+}
+
+// Game::tryMove with the reference's check order (game.cpp:583-662); err codes 1..7
+__global__ void try_move_kernel(EnvView e, const int32_t *__restrict__ player, const int32_t *__restrict__ dice,
+                                const int32_t *__restrict__ origin, const int32_t *__restrict__ dest, int32_t *__restrict__ err)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t p[8];
+    load_planes(e, g, p);
+    const int pl = player[g] == 1 ? 1 : 0, d = dice[g], o = origin[g], t = dest[g];
+    Side own, opp;
+    split_sides(p, pl, own, opp);
+    const uint32_t barbit = pl ? (1u << 25) : 1u;
+    const uint32_t own_any = any_of(own);
+    int code = 0;
+    // isValidOrigin (game.cpp:416-457)
+    bool vo;
+    if (own_any & barbit) vo = (o == (pl ? 25 : 0));
+    else vo = (o >= 1 && o <= 24) && ((own_any >> o) & 1u);
+    if (!vo) code = 1;
+    else if (o < 0 || o > 25) code = 2;
+    else if (t < 0 || t > 25) code = 3;
+    else {
+        const int diff = o - t;
+        if (t != 0 && t != 25) {
+            const int adiff = diff < 0 ? -diff : diff;
+            if ((pl ? -diff : diff) > 0) code = 4;            // diff * (-multi) < 0
+            else if (d != adiff) code = 5;
+            else if ((ge2_of(opp) >> t) & 1u) code = 6;       // t in 1..24 here
+            else {
+                dec_at(own, 1u << o);                          // bar or point: same plane arithmetic
+                const uint32_t md = 1u << t;
+                const uint32_t hm = md & opp.b[0] & ~ge2_of(opp);
+                opp.b[0] ^= hm;
+                inc_at(opp, hm ? (pl ? 1u : (1u << 25)) : 0u);
+                inc_at(own, md);
+            }
+        } else {
+            // bear-off branch (game.cpp:636-648): only "origin on the board" is re-checked;
+            // the checker leaves the origin and the MOVER's freed counter grows, whatever t is
+            if (o == 0 || o == 25) code = 7;
+            else { dec_at(own, 1u << o); inc_at(own, pl ? 1u : (1u << 25)); }
+        }
+    }
+    if (code == 0) {
+        join_sides(own, opp, pl, p);
+        store_planes(e, g, p);
+    }
+    err[g] = code;
+}
+
+__global__ void legal_moves_kernel(EnvView e, const int32_t *__restrict__ player, const int32_t *__restrict__ die,
+                                   int32_t *__restrict__ n_out, int8_t *__restrict__ pairs)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t p[8];
+    load_planes(e, g, p);
+    const int pl = player[g] == 1 ? 1 : 0, d = die[g];
+    Side own, opp;
+    split_sides(p, pl, own, opp);
+    uint32_t m = (d >= 1 && d <= 6) ? legal_origins(own, opp, pl, d) : 0u;
+    int n = 0;
+    while (m) {
+        const int o = __ffs(m) - 1; m &= m - 1;
+        int t = pl ? o - d : o + d;
+        t = t < 0 ? 0 : (t > 25 ? 25 : t);
+        pairs[(g * 26 + n) * 2] = (int8_t)o; pairs[(g * 26 + n) * 2 + 1] = (int8_t)t;
+        ++n;
+    }
+    n_out[g] = n;
+}
+
+// marks the mover's direction in the packed sequences of the last step (bit 29) -- see unpack_seq
+__global__ void tag_chosen_seq_kernel(EnvView e, const uint32_t *__restrict__ turn_before)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < e.n && (turn_before[g] & 1u)) e.chosen_seq[g] |= 1u << 29;
+}
+
+}  // namespace
+
+// ================================================================================================
+//                                           C ABI
+// ================================================================================================
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            g_hip_err = std::string(#call) + ": " + hipGetErrorString(_e);             \
+            return BGAMD_E_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+struct bgamd_env {
+    int device = 0;
+    EnvView v{};
+    uint32_t *turn_before = nullptr;       // [n] mover of the last step
+    float *d_w = nullptr;                  // raw weights 25601
+    float4 *d_wl = nullptr;                // fp32 MFMA layout [99][64]
+    bool has_weights = false;
+    int n_cu = 256;
+    // kernel timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;            // pairs
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
+    double t_ms[4] = {0, 0, 0, 0};
+    uint64_t t_n[4] = {0, 0, 0, 0};
+};
+
+namespace {
+inline dim3 grid1(long long n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+int flush_events(bgamd_env *env)
+{
+    for (size_t i = 0; i < env->ev_used; ++i) {
+        HIPCHK(hipEventSynchronize(env->ev[2 * i + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, env->ev[2 * i], env->ev[2 * i + 1]));
+        env->t_ms[env->ev_kind[i]] += ms;
+        env->t_n[env->ev_kind[i]] += 1;
+    }
+    env->ev_used = 0;
+    return BGAMD_OK;
+}
+
+struct KTimer {
+    bgamd_env *env; hipStream_t s; size_t slot; bool on;
+    KTimer(bgamd_env *e, hipStream_t st, int kind) : env(e), s(st), slot(0), on(e->timing)
+    {
+        if (!on) return;
+        if (env->ev_used * 2 + 2 > env->ev.size()) {
+            if (env->ev.size() >= 2 * 8192) { flush_events(env); }
+            else {
+                for (int i = 0; i < 2; ++i) { hipEvent_t x; hipEventCreate(&x); env->ev.push_back(x); }
+                env->ev_kind.push_back(0);
+            }
+        }
+        slot = env->ev_used++;
+        env->ev_kind[slot] = kind;
+        hipEventRecord(env->ev[2 * slot], s);
+    }
+    ~KTimer() { if (on) hipEventRecord(env->ev[2 * slot + 1], s); }
+};
+}  // namespace
+
+extern "C" {
+
+int bgamd_version(void) { return 100; }
+
+const char *bgamd_error_string(int code)
+{
+    switch (code) {
+    case BGAMD_OK: return "ok";
+    case BGAMD_E_INVALID: return "invalid argument";
+    case BGAMD_E_HIP: return "HIP runtime error";
+    case BGAMD_E_NODEVICE: return "no usable gfx950 device";
+    case BGAMD_E_ARENA: return "candidate arena overflow";
+    case BGAMD_E_STATE: return "state with |count| > 15";
+    case BGAMD_E_NOWEIGHTS: return "weights not loaded";
+    default: return "unknown error";
+    }
+}
+const char *bgamd_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int bgamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed, uint64_t lane_offset,
+                     uint64_t lane_stride, int64_t arena_rows)
+{
+    if (!out || n_games <= 0 || n_games > (1ll << 30)) return BGAMD_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BGAMD_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BGAMD_E_NODEVICE;
+    bgamd_env *env = new bgamd_env();
+    env->device = device;
+    env->n_cu = prop.multiProcessorCount;
+    EnvView &v = env->v;
+    v.n = n_games; v.seed = seed; v.lane_offset = lane_offset; v.lane_stride = lane_stride ? lane_stride : (uint64_t)n_games;
+    long long cap = arena_rows > 0 ? arena_rows : n_games * 256;
+    if (cap < 65536) cap = 65536;
+    if (cap > (1ll << 31) - 64) cap = (1ll << 31) - 64;
+    v.cap = cap;
+    const size_t n = (size_t)n_games;
+    HIPCHK(hipMalloc(&v.planes, n * 8 * 4));
+    HIPCHK(hipMalloc(&v.meta, n * 4));
+    HIPCHK(hipMalloc(&v.ply, n * 4));
+    HIPCHK(hipMalloc(&v.episode, n * 4));
+    HIPCHK(hipMalloc(&v.flags, n * 4));
+    HIPCHK(hipMalloc(&v.cand_off, n * 4));
+    HIPCHK(hipMalloc(&v.cand_cnt, n * 4));
+    HIPCHK(hipMalloc(&v.chosen, n * 4));
+    HIPCHK(hipMalloc(&v.chosen_seq, n * 4));
+    HIPCHK(hipMalloc(&v.chosen_val, n * 4));
+    HIPCHK(hipMalloc(&env->turn_before, n * 4));
+    HIPCHK(hipMalloc(&v.rows, (size_t)cap * 32));
+    HIPCHK(hipMalloc(&v.seqs, (size_t)cap * 4));
+    HIPCHK(hipMalloc(&v.values, (size_t)cap * 4));
+    HIPCHK(hipMalloc(&v.counters, C_COUNT * 8));
+    HIPCHK(hipMalloc(&env->d_w, N_PARAMS * 4));
+    HIPCHK(hipMalloc(&env->d_wl, EVAL_LDS_BYTES));
+    HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_BYTES));
+    *out = env;
+    return bgamd_env_reset(env, nullptr);
+}
+
+int bgamd_env_destroy(bgamd_env *env)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipSetDevice(env->device);
+    hipDeviceSynchronize();
+    EnvView &v = env->v;
+    void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
+                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (hipEvent_t e : env->ev) hipEventDestroy(e);
+    delete env;
+    return BGAMD_OK;
+}
+
+int64_t bgamd_env_num_games(const bgamd_env *env) { return env ? env->v.n : 0; }
+
+int bgamd_env_reset(bgamd_env *env, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(env->device));
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v);
+    HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, s));
+    HIPCHK(hipMemsetAsync(env->turn_before, 0, (size_t)env->v.n * 4, s));
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_set_states(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, void *stream)
+{
+    if (!env || (!d_states28 && !d_turn)) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(set_states_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_states28, d_turn);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_get_states(bgamd_env *env, int32_t *d_states28, int32_t *d_turn, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(get_states_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_states28, d_turn);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_get_flags(bgamd_env *env, int32_t *d_flags, void *stream)
+{
+    if (!env || !d_flags) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(get_flags_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_flags);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice, void *stream)
+{
+    if (!env || !d_dice) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_dice, (int32_t *)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+int bgamd_env_get_dice(bgamd_env *env, int32_t *d_dice, void *stream)
+{
+    if (!env || !d_dice) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, d_dice, 0);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+int bgamd_env_roll(bgamd_env *env, int advance_ply, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, (int32_t *)nullptr, advance_ply ? 2 : 1);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+static int launch_emit(bgamd_env *env, int flags, int with_seq, const int32_t *ov_player, const int32_t *ov_dice, hipStream_t s)
+{
+    HIPCHK(hipMemsetAsync(&env->v.counters[C_ARENA_TOP], 0, 8, s));
+    {
+        KTimer t(env, s, 0);
+        hipLaunchKernelGGL(emit_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, with_seq, ov_player, ov_dice);
+    }
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_enumerate(bgamd_env *env, const int32_t *d_player, const int32_t *d_dice, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    return launch_emit(env, 0, 1, d_player, d_dice, (hipStream_t)stream);
+}
+
+static int check_err_flags(bgamd_env *env, unsigned long long f)
+{
+    (void)env;
+    if (f & ERRF_ARENA) return BGAMD_E_ARENA;
+    if (f & ERRF_STATE) return BGAMD_E_STATE;
+    return BGAMD_OK;
+}
+
+int64_t bgamd_env_candidates_info(bgamd_env *env, int64_t *d_offsets, int32_t *d_counts, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cand_info_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, d_offsets, d_counts);
+    unsigned long long h[C_COUNT];
+    HIPCHK(hipMemcpyAsync(h, env->v.counters, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int rc = check_err_flags(env, h[C_ERR]);
+    if (rc) return rc;
+    return (int64_t)h[C_ARENA_TOP];
+}
+
+int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28, int8_t *d_seq,
+                              int32_t *d_seq_len, void *stream)
+{
+    if (!env || first < 0 || n_rows < 0 || first + n_rows > env->v.cap) return BGAMD_E_INVALID;
+    if (n_rows == 0) return BGAMD_OK;
+    hipLaunchKernelGGL(rows_read_kernel, grid1(n_rows, 128), dim3(128), 0, (hipStream_t)stream, env->v.rows, env->v.seqs,
+                       (long long)first, (long long)n_rows, d_states28, d_seq, d_seq_len);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+static int snapshot_turn(bgamd_env *env, hipStream_t s)
+{
+    HIPCHK(hipMemcpyAsync(env->turn_before, env->v.meta, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
+    return BGAMD_OK;
+}
+
+int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = snapshot_turn(env, s);
+    if (rc) return rc;
+    {
+        KTimer t(env, s, 3);
+        hipLaunchKernelGGL(step_random_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, d_choice_u32);
+    }
+    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, env->turn_before);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_load_weights(bgamd_env *env, const float *h_weights)
+{
+    if (!env || !h_weights) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    std::vector<float> wl((size_t)K_STEPS * 64 * 4);
+    relayout_w1_f32(h_weights, wl.data());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(env->d_w, h_weights, N_PARAMS * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_wl, wl.data(), EVAL_LDS_BYTES, hipMemcpyHostToDevice));
+    env->has_weights = true;
+    return BGAMD_OK;
+}
+
+static int launch_eval(bgamd_env *env, int precision, const unsigned long long *n_rows_ptr, long long n_rows_imm,
+                       const uint4 *rows, float *values, hipStream_t s)
+{
+    if (precision != BGAMD_F32) return BGAMD_E_INVALID;     // bf16 path: later round
+    const float *b1 = env->d_w + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    {
+        KTimer t(env, s, 1);
+        hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(256), EVAL_LDS_BYTES, s, rows, n_rows_ptr,
+                           n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
+                           (const float4 *)env->d_wl, b1, w2, b2, values);
+    }
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    if (!env->has_weights) return BGAMD_E_NOWEIGHTS;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = snapshot_turn(env, s);
+    if (rc) return rc;
+    rc = launch_emit(env, flags, 1, nullptr, nullptr, s);
+    if (rc) return rc;
+    rc = launch_eval(env, precision, &env->v.counters[C_ARENA_TOP], 0, env->v.rows, env->v.values, s);
+    if (rc) return rc;
+    {
+        KTimer t(env, s, 2);
+        hipLaunchKernelGGL(select_apply_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, epsilon, 1);
+    }
+    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, env->turn_before);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq, int32_t *d_seq_len,
+                          float *d_value, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(last_choice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_chosen, d_count,
+                       d_seq, d_seq_len, d_value);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[6])
+{
+    if (!env || !h_out) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long h[C_COUNT];
+    HIPCHK(hipMemcpy(h, env->v.counters, sizeof h, hipMemcpyDeviceToHost));
+    h_out[0] = h[C_STEPS]; h_out[1] = h[C_FINISHED]; h_out[2] = h[C_P1WINS];
+    h_out[3] = h[C_CAND_RAW]; h_out[4] = h[C_ROWS_EVAL]; h_out[5] = h[C_ERR];
+    return check_err_flags(env, h[C_ERR]);
+}
+
+int bgamd_env_reset_stats(bgamd_env *env, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, (hipStream_t)stream));
+    return BGAMD_OK;
+}
+
+int bgamd_env_try_move(bgamd_env *env, const int32_t *d_player, const int32_t *d_dice, const int32_t *d_origin,
+                       const int32_t *d_dest, int32_t *d_err, void *stream)
+{
+    if (!env || !d_player || !d_dice || !d_origin || !d_dest || !d_err) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(try_move_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_player, d_dice,
+                       d_origin, d_dest, d_err);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t *d_die, int32_t *d_n, int8_t *d_pairs,
+                          void *stream)
+{
+    if (!env || !d_player || !d_die || !d_n || !d_pairs) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(legal_moves_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_player, d_die,
+                       d_n, d_pairs);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, float *d_out198, void *stream)
+{
+    if (!d_states28 || !d_out198 || n < 0) return BGAMD_E_INVALID;
+    if (n == 0) return BGAMD_OK;
+    hipLaunchKernelGGL(encode_states_kernel, grid1(n, 128), dim3(128), 0, (hipStream_t)stream, d_states28, d_turn, (long long)n,
+                       d_out198);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, int64_t n, int precision,
+                   float *d_values, void *stream)
+{
+    if (!env || !d_states28 || !d_values || n < 0 || n > env->v.cap) return BGAMD_E_INVALID;
+    if (!env->has_weights) return BGAMD_E_NOWEIGHTS;
+    if (n == 0) return BGAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // the candidate arena doubles as scratch for caller-provided states
+    hipLaunchKernelGGL(pack_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_turn, (long long)n, env->v.rows,
+                       &env->v.counters[C_ERR]);
+    return launch_eval(env, precision, nullptr, (long long)n, env->v.rows, d_values, s);
+}
+
+int bgamd_env_time_kernels(bgamd_env *env, int enable)
+{
+    if (!env) return BGAMD_E_INVALID;
+    if (!enable && env->timing) flush_events(env);
+    env->timing = enable != 0;
+    return BGAMD_OK;
+}
+
+int bgamd_env_kernel_times(bgamd_env *env, double h_ms[4], uint64_t h_launches[4])
+{
+    if (!env) return BGAMD_E_INVALID;
+    const int rc = flush_events(env);
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) {
+        if (h_ms) h_ms[i] = env->t_ms[i];
+        if (h_launches) h_launches[i] = env->t_n[i];
+        env->t_ms[i] = 0; env->t_n[i] = 0;
+    }
+    return BGAMD_OK;
+}
+
+}  // extern "C"

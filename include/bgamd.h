@@ -1,0 +1,143 @@
+/* bgamd.h -- C ABI of the MI355X-native batched backgammon env step (libbgamd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of romanoshiliarhopoulos/Backgammon-Engine:
+ * the self-play env step.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference root).  The reference crosses Python<->C++ through the
+ * pybind11 module `backgammon_env` (cppsrc/backgammon_bindings.cpp:41-94); a maintainer binds
+ * these symbols instead (ctypes stub in INTEGRATION.md, shipped as
+ * backgammon-engine_amd/backgammon_env/).
+ *
+ * Conventions
+ *   - plain C, no torch types.  Every `d_*` pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); `h_*` pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     stream-ordered; nothing synchronises unless stated.
+ *   - return value: 0 = ok, negative = BGAMD_E_* (bgamd_error_string()).
+ *   - a state is int32[28] = [board24 (+P1/-P2), bar1, bar2, off1, off2]   (game.hpp:16-28);
+ *     |count| <= 15.  turn: 0 = PLAYER1, 1 = PLAYER2 (player.hpp:14-18).
+ *   - one host thread drives one env; one env lives on one device.
+ */
+#ifndef BGAMD_H
+#define BGAMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bgamd_env bgamd_env;
+
+enum {
+    BGAMD_OK = 0,
+    BGAMD_E_INVALID = -1,     /* bad argument                                         */
+    BGAMD_E_HIP = -2,         /* a HIP runtime call failed (see bgamd_last_hip_error) */
+    BGAMD_E_NODEVICE = -3,    /* no usable gfx950 device                              */
+    BGAMD_E_ARENA = -4,       /* candidate arena overflow (raise arena_rows)          */
+    BGAMD_E_STATE = -5,       /* a state had |count| > 15                             */
+    BGAMD_E_NOWEIGHTS = -6    /* greedy step / evaluate before bgamd_env_load_weights */
+};
+
+/* step flags */
+enum {
+    BGAMD_ROLL = 1,           /* draw this turn's dice from the Philox stream (Game::rollDice,
+                                 game.cpp:665-670); without it the dice set by
+                                 bgamd_env_set_dice are used (Game::setDice, game.cpp:9-12)     */
+    BGAMD_AUTO_RESET = 2,     /* a finished game restarts (new episode, opening roll);
+                                 without it a finished game stays finished and is skipped      */
+    BGAMD_NO_FLIP = 4         /* do not flip the turn / advance ply (make_move semantics,
+                                 model.py:180-222, for the scalar Game surface)                */
+};
+
+enum { BGAMD_F32 = 0, BGAMD_BF16 = 1 };   /* value-net arithmetic */
+
+int bgamd_version(void);
+const char *bgamd_error_string(int code);
+const char *bgamd_last_hip_error(void);
+int bgamd_device_count(void);
+
+/* ---- env lifetime ---------------------------------------------------------------------
+ * Replaces: Game::Game(int) game.cpp:44-56 for n_games boards at once.
+ * Lane g plays game_id = lane_offset + g + episode * lane_stride; dice/choice words are
+ * Philox4x32-10(key = seed, counter = (game_id, ply, stream)) so a shard's games do not
+ * depend on how many shards there are.  arena_rows = capacity of the candidate arena
+ * (0 = default 256 rows per game, min 65 536). */
+int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed,
+                     uint64_t lane_offset, uint64_t lane_stride, int64_t arena_rows);
+int bgamd_env_destroy(bgamd_env *env);
+int64_t bgamd_env_num_games(const bgamd_env *env);
+
+/* All lanes: episode 0, ply 0, start position (Game::populateBoard game.cpp:240-252), turn from
+ * the opening roll protocol of play_game (train.py:89-97) on the OPENING stream. */
+int bgamd_env_reset(bgamd_env *env, void *stream);
+
+/* ---- state access (getGameBoard/getJailedCount/getBornOffCount/getTurn/setGameBoard/
+ *      setBorneOffPieces/setTurn, bindings.cpp:64-85) ------------------------------------- */
+int bgamd_env_set_states(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, void *stream);
+int bgamd_env_get_states(bgamd_env *env, int32_t *d_states28, int32_t *d_turn, void *stream);
+/* is_game_over (bindings.cpp:11-16) on the current boards: bit0 = over, bit1 = winner (0/1),
+ * bit2 = lane frozen (finished without AUTO_RESET); bits4-5 = over/winner flags of the last step
+ * (set even when the lane was auto-reset). d_states28 may be NULL in set_states (turn only). */
+int bgamd_env_get_flags(bgamd_env *env, int32_t *d_flags, void *stream);
+int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice /*[n,2]*/, void *stream);   /* setDice      */
+int bgamd_env_get_dice(bgamd_env *env, int32_t *d_dice /*[n,2]*/, void *stream);         /* get_last_dice */
+/* roll_dice: dice of (game_id, ply) on the TURN stream; advance_ply != 0 post-increments ply so that
+ * repeated calls draw fresh dice (the scalar Game surface), 0 leaves ply to the step functions. */
+int bgamd_env_roll(bgamd_env *env, int advance_ply, void *stream);
+
+/* ---- enumeration: Game::evaluateTurnSequences for every lane (game.cpp:193-222) -----------
+ * Fills the env's candidate arena in REFERENCE ORDER (duplicates kept) for the lanes' current
+ * turn and dice, or for the explicit (player, d1, d2) arguments of the reference call.  Afterwards:
+ *   bgamd_env_candidates_info : d_offsets[n] (first row of lane g), d_counts[n]; returns total rows
+ *                               (synchronises the stream)
+ *   bgamd_env_candidates_read : rows [first, first+n_rows) unpacked to int32 states [n_rows,28] and
+ *                               int8 sequences [n_rows,4,2] ((origin,dest), -1 padded), lengths. */
+int bgamd_env_enumerate(bgamd_env *env, const int32_t *d_player /*[n] or NULL*/, const int32_t *d_dice /*[n,2] or NULL*/,
+                        void *stream);
+int64_t bgamd_env_candidates_info(bgamd_env *env, int64_t *d_offsets, int32_t *d_counts, void *stream);
+int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28,
+                              int8_t *d_seq, int32_t *d_seq_len, void *stream);
+
+/* ---- the env step ---------------------------------------------------------------------------
+ * One turn of every live lane: (roll) -> enumerate -> choose -> apply -> terminal check ->
+ * (auto-reset | flip turn), i.e. the body of play_game's loop (train.py:103-121).
+ *   random: uniform over the reference-order list, k = (u32 * C) >> 32 with u32 from d_choice_u32
+ *           (per lane) or, when NULL, from the Philox TURN stream         (benchmark.py:54-61)
+ *   greedy: TDLGammonModel.make_move (model.py:180-222): value net on every afterstate with the
+ *           MOVER's turn bit, argmax (P1) / argmin (P2), first index wins ties; epsilon > 0 draws
+ *           the exploration test and index from the TURN stream.  precision BGAMD_F32 | BGAMD_BF16.
+ * Per-lane results of the last step: chosen reference-order index (-1 = no move), packed sequence,
+ * candidate count, value of the chosen afterstate. */
+int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
+int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);
+int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);
+int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq /*[n,4,2]*/,
+                          int32_t *d_seq_len, float *d_value, void *stream);
+
+/* counters since create/reset_stats (synchronises): [steps, games_finished, p1_wins, candidates_raw,
+ * rows_evaluated, error_flags] */
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[6]);
+int bgamd_env_reset_stats(bgamd_env *env, void *stream);
+
+/* single-checker surface for lane-wise moves: Game::tryMove (game.cpp:573-663) and
+ * Game::legalMoves (game.cpp:80-105).  d_err: 0 ok, 1..7 = the reference's messages in source order. */
+int bgamd_env_try_move(bgamd_env *env, const int32_t *d_player, const int32_t *d_dice, const int32_t *d_origin,
+                       const int32_t *d_dest, int32_t *d_err, void *stream);
+int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t *d_die,
+                          int32_t *d_n, int8_t *d_pairs /*[n,26,2]*/, void *stream);
+
+/* ---- stateless operators ----------------------------------------------------------------------
+ * _encode_states_np (model.py:111-144) and forward (model.py:63-67) on caller-provided states. */
+int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, float *d_out198, void *stream);
+int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, int64_t n,
+                   int precision, float *d_values, void *stream);
+
+/* kernel timing hook for bench.py: brackets the value-net kernel of each greedy step with HIP
+ * events on `stream`; bgamd_env_eval_time_ms returns the accumulated milliseconds and launch
+ * count since the last call (synchronises). */
+int bgamd_env_time_kernels(bgamd_env *env, int enable);
+int bgamd_env_kernel_times(bgamd_env *env, double h_ms[4], uint64_t h_launches[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

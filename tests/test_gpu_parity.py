@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded inputs,
+against the golden vectors captured from the unmodified reference, and -- at full size -- through
+size-independent properties.  Integer work is bit-exact; value-net outputs within 1e-5 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SEED = 20240603
+START = [2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2]
+
+
+@pytest.fixture(scope="module")
+def bg():
+    import backgammon_env
+    return backgammon_env
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+# ---- enumeration -----------------------------------------------------------------------------------
+
+def test_g1_edge_calls_bit_exact(bg, golden_dir):
+    """Hand-built edge boards (bear-off overrun asymmetry, bar entry, stuck positions, mid-sequence
+    wins): ordered sequences + afterstates identical to the reference's evaluateTurnSequences."""
+    g = np.load(os.path.join(golden_dir, "g1_edge_calls.npz"))
+    inp, counts, off = g["inputs"].astype(np.int32), g["counts"], g["off"]
+    n = len(inp)
+    env = bg.VecGame(n, arena_rows=int(off[-1]) + 65536)
+    env.set_states(inp[:, :28], inp[:, 28])
+    offs, cnts, st, sq, ln = [_np(x) for x in env.enumerate(player=inp[:, 28], dice=inp[:, 29:31])]
+    assert (cnts == counts).all()
+    assert offs.sum() >= 0 and cnts.sum() == off[-1]
+    for i in range(n):
+        a, b = int(offs[i]), int(offs[i]) + int(cnts[i])
+        assert (st[a:b] == g["states"][off[i]:off[i + 1]]).all(), g["names"][i]
+        assert (sq[a:b] == g["seq"][off[i]:off[i + 1]]).all(), g["names"][i]
+        assert (ln[a:b] == (g["seq"][off[i]:off[i + 1], :, 0] >= 0).sum(1)).all()
+
+
+def test_enumerate_vs_oracle_4096(bg, O):
+    """Config 2 size: 4 096 mid-game boards, every lane's full ordered enumeration vs the oracle."""
+    n = 4096
+    env = bg.VecGame(n, seed=SEED, arena_rows=4 << 20)
+    for _ in range(37):
+        env.step_random()
+    st0, t0 = _np(env.states()), _np(env.turns())
+    env.roll()
+    dice = _np(env.dice())
+    offs, cnts, st, sq, ln = [_np(x) for x in env.enumerate()]
+    tot = 0
+    for lane in range(n):
+        s = O.State.from28(st0[lane], t0[lane])
+        q, l, a = O.evaluate_turn_sequences(s, int(t0[lane]), int(dice[lane, 0]), int(dice[lane, 1]))
+        assert cnts[lane] == len(l), lane
+        o = int(offs[lane])
+        assert (st[o:o + len(l)] == a).all(), lane
+        assert (sq[o:o + len(l)] == q).all() and (ln[o:o + len(l)] == l).all(), lane
+        tot += len(l)
+    assert tot == cnts.sum()
+    assert (_np(env.states()) == st0).all()          # enumeration does not mutate (tests.cpp:390-399)
+
+
+def test_start_position_counts(bg, golden_dir):
+    t = np.load(os.path.join(golden_dir, "g2_start_counts.npz"))["counts"]
+    env = bg.VecGame(72)
+    pl = np.repeat([0, 1], 36).astype(np.int32)
+    dice = np.array([[a, b] for _ in (0, 1) for a in range(1, 7) for b in range(1, 7)], dtype=np.int32)
+    env.set_states(np.tile(np.array(START + [0, 0, 0, 0], dtype=np.int32), (72, 1)), pl)
+    _, cnts, _, _, _ = env.enumerate(player=pl, dice=dice)
+    assert (_np(cnts).reshape(2, 6, 6) == t).all()
+
+
+# ---- random-policy trajectories ---------------------------------------------------------------------
+
+def test_g3_reference_trajectories(bg, golden_dir):
+    """200 games played by the unmodified reference on injected Philox dice/choices: the env, started
+    from its own reset (opening roll) and stepping with its own streams, reproduces every state."""
+    g = np.load(os.path.join(golden_dir, "g3_random_trajectories.npz"))
+    rows, stride = g["rows"], int(g["stride"])
+    env = bg.VecGame(stride, seed=int(g["seed"]), lane_stride=stride)
+    by_lane = [rows[rows[:, 0] == lane] for lane in range(stride)]
+    T = max(len(r) for r in by_lane)
+    assert (_np(env.turns()) == np.array([r[0, 30] for r in by_lane])).all()     # opening protocol
+    for t in range(T):
+        st, tn = _np(env.states()), _np(env.turns())
+        for lane, r in enumerate(by_lane):
+            if t < len(r):
+                assert (st[lane] == r[t, 2:30]).all() and tn[lane] == r[t, 30], (lane, t)
+        env.step_random(auto_reset=False)
+        lc = env.last_choice()
+        ch, cn, dice, fl = _np(lc["chosen"]), _np(lc["count"]), _np(env.dice()), _np(env.flags())
+        for lane, r in enumerate(by_lane):
+            if t < len(r):
+                assert (dice[lane] == r[t, 31:33]).all() and cn[lane] == r[t, 33] and ch[lane] == r[t, 34], (lane, t)
+                assert (fl[lane] & 1) == r[t, 35] and (not r[t, 35] or ((fl[lane] >> 1) & 1) == r[t, 36])
+    s = env.stats()
+    assert s["games_finished"] == stride and s["steps"] == len(rows)
+    assert s["p1_wins"] == sum(int(r[-1, 36] == 0) for r in by_lane)
+    assert s["candidates_raw"] == int(rows[:, 33].sum())
+
+
+def test_random_trajectories_vs_oracle_4096(bg, O):
+    """Config 2: B = 4 096, auto-reset, every lane's state checked after EVERY step for 200 steps."""
+    n, steps = 4096, 200
+    env = bg.VecGame(n, seed=SEED)
+    snaps = np.zeros((steps, n, 29), dtype=np.int32)
+    flags = np.zeros((steps, n), dtype=np.int32)
+    for t in range(steps):
+        env.step_random()
+        snaps[t, :, :28] = _np(env.states())
+        snaps[t, :, 28] = _np(env.turns())
+        flags[t] = (_np(env.flags()) >> 4) & 3
+    fin = ctot = 0
+    for lane in range(n):
+        ref, f, c, _ = O.lane_run(SEED, lane, n, steps, 0)
+        assert (ref[:, :29] == snaps[:, lane]).all(), lane
+        assert (ref[:, 29] == flags[:, lane]).all(), lane
+        fin += f
+        ctot += c
+    s = env.stats()
+    assert s["games_finished"] == fin and s["candidates_raw"] == ctot and s["steps"] == n * steps
+
+
+def test_shard_invariance(bg):
+    """lane g of shard r plays global game r*B/R + g -- results do not depend on R."""
+    n, steps = 1024, 60
+    whole = bg.VecGame(n, seed=7)
+    parts = [bg.VecGame(n // 4, seed=7, lane_offset=r * (n // 4), lane_stride=n) for r in range(4)]
+    for _ in range(steps):
+        whole.step_random()
+        for p in parts:
+            p.step_random()
+    got = np.concatenate([_np(p.states()) for p in parts])
+    assert (got == _np(whole.states())).all()
+    assert sum(p.stats()["games_finished"] for p in parts) == whole.stats()["games_finished"]
+
+
+def test_full_size_properties_65536(bg):
+    """BASELINE size: 65 536 lanes. Checker conservation, determinism, turn sanity after 150 steps."""
+    n = 65536
+    a, b = bg.VecGame(n, seed=11), bg.VecGame(n, seed=11)
+    for _ in range(150):
+        a.step_random()
+        b.step_random()
+    sa = _np(a.states())
+    assert (sa == _np(b.states())).all() and (_np(a.turns()) == _np(b.turns())).all()
+    p1 = np.clip(sa[:, :24], 0, None).sum(1) + sa[:, 24] + sa[:, 26]
+    p2 = np.clip(-sa[:, :24], 0, None).sum(1) + sa[:, 25] + sa[:, 27]
+    assert (p1 == 15).all() and (p2 == 15).all()
+    assert (sa[:, 26] < 15).all() and (sa[:, 27] < 15).all()      # finished games were reset
+    st = a.stats()
+    assert st["steps"] == n * 150 and st["games_finished"] > 0 and st["error_flags"] == 0
+    assert 0.3 < st["p1_wins"] / st["games_finished"] < 0.7       # CLAUDE.md:70 random-vs-random sanity
+
+
+# ---- single-checker surface ------------------------------------------------------------------------
+
+def test_try_move_and_legal_moves_vs_oracle(bg, O):
+    n = 2048
+    env = bg.VecGame(n, seed=3)
+    for _ in range(45):
+        env.step_random()
+    rng = np.random.RandomState(0)
+    st, tn = _np(env.states()), _np(env.turns())
+    for die in range(1, 7):
+        for pl in (0, 1):
+            cnt, pairs = env.legal_moves(np.full(n, pl), np.full(n, die))
+            cnt, pairs = _np(cnt), _np(pairs)
+            for lane in range(0, n, 9):
+                exp = O.legal_moves(O.State.from28(st[lane], tn[lane]), pl, die)
+                assert [tuple(x) for x in pairs[lane, :cnt[lane]].tolist()] == exp
+    # probes: half legal moves, half arbitrary
+    pl = rng.randint(0, 2, n); dice = rng.randint(1, 7, n)
+    org = rng.randint(-1, 27, n); dst = rng.randint(-1, 27, n)
+    for lane in range(0, n, 2):
+        mv = O.legal_moves(O.State.from28(st[lane], tn[lane]), int(tn[lane]), int(dice[lane]))
+        if mv:
+            pl[lane] = tn[lane]
+            org[lane], dst[lane] = mv[rng.randint(len(mv))]
+    err = _np(env.try_move(pl, dice, org, dst))
+    after = _np(env.states())
+    n_ok = 0
+    for lane in range(n):
+        s = O.State.from28(st[lane], tn[lane])
+        ok, msg = O.try_move(s, int(pl[lane]), int(dice[lane]), int(org[lane]), int(dst[lane]))
+        assert bg.ERR_MESSAGES[int(err[lane])] == msg, (lane, err[lane], msg)
+        assert (after[lane] == s.to28()).all(), lane
+        n_ok += ok
+    assert n_ok > n // 4
+
+
+# ---- encoder + value net ------------------------------------------------------------------------------
+
+def test_encoder_bit_exact(bg, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_encoder_rows.npz"))
+    env = bg.VecGame(1)
+    X = _np(env.encode(g["states"].astype(np.int32), g["turn"]))
+    assert X.dtype == np.float32 and np.array_equal(X, g["X"])
+
+
+def test_values_vs_reference_model(bg, O, golden_dir, weights):
+    """fp32 MFMA value net vs the reference PyTorch model (fixture) and the fp64 oracle: <= 1e-5."""
+    g = np.load(os.path.join(golden_dir, "g5_values.npz"))
+    env = bg.VecGame(1, arena_rows=1 << 20)
+    env.load_weights(weights)
+    v = _np(env.evaluate(g["states"].astype(np.int32), g["turn"]))
+    assert np.abs(v - g["v32"]).max() < 1e-5
+    assert np.abs(v - g["v64"]).max() < 1e-5
+    # ragged sizes around the 32-row tile, and a large batch
+    rng = np.random.RandomState(1)
+    for m in (1, 31, 32, 33, 97, 50000):
+        idx = rng.randint(0, len(g["turn"]), m)
+        vv = _np(env.evaluate(g["states"][idx].astype(np.int32), g["turn"][idx]))
+        assert np.abs(vv - g["v64"][idx]).max() < 1e-5, m
+
+
+def _check_greedy_step(O, w, pre, pt, dice, post, lanes):
+    for lane in lanes:
+        s = O.State.from28(pre[lane], pt[lane])
+        _, _, cand = O.evaluate_turn_sequences(s, int(pt[lane]), int(dice[lane, 0]), int(dice[lane, 1]))
+        if len(cand) == 0:
+            assert (post[lane] == pre[lane]).all()
+            continue
+        v = O.forward_f64(w, O.encode(cand, int(pt[lane])))
+        k = [i for i in range(len(cand)) if (cand[i] == post[lane]).all()]
+        assert k, lane
+        best = v.max() if pt[lane] == 0 else v.min()
+        assert abs(v[k[0]] - best) < 1e-5, (lane, v[k[0]], best)
+
+
+def test_greedy_steps_value_optimal(bg, O, weights):
+    """Config 3 semantics at 4 096 lanes: after each greedy step every applied afterstate is a legal
+    candidate whose oracle value is within 1e-5 of the arg-max (P1) / arg-min (P2)."""
+    n = 4096
+    env = bg.VecGame(n, seed=SEED)
+    env.load_weights(weights)
+    for t in range(40):
+        pre, pt = _np(env.states()), _np(env.turns())
+        was_live = (_np(env.flags()) & 4) == 0
+        env.step_greedy(auto_reset=False)
+        post, dice = _np(env.states()), _np(env.dice())
+        if t % 4 == 0:
+            _check_greedy_step(O, weights, pre, pt, dice, post, [l for l in range(t % 7, n, 29) if was_live[l]])
+        live = (_np(env.flags()) & 4) == 0
+        assert (_np(env.turns()) != pt)[live].all()
+        assert (post == pre)[~was_live].all()
+    assert env.stats()["error_flags"] == 0
+
+
+def test_g5_reference_greedy_games(bg, golden_dir, weights):
+    """Games played by the reference make_move: wherever its best/second-best gap exceeds 2e-6 the env
+    picks the identical afterstate (index, sequence and board)."""
+    g = np.load(os.path.join(golden_dir, "g5_greedy_trajectories.npz"))
+    rows = g["rows"]
+    n = len(rows)
+    env = bg.VecGame(n, arena_rows=max(int(rows[:, 33].sum()) + 65536, 1 << 20))
+    env.load_weights(weights)
+    env.set_states(rows[:, 2:30], rows[:, 30])
+    env.set_dice(rows[:, 31:33])
+    env.step_greedy(roll=False, auto_reset=False)
+    post = _np(env.states())
+    lc = env.last_choice()
+    ch, cn = _np(lc["chosen"]), _np(lc["count"])
+    assert (cn == rows[:, 33]).all()
+    clear = (rows[:, 65] > 2000) | (rows[:, 33] <= 1)
+    assert clear.mean() > 0.9
+    assert (post[clear] == rows[clear, 37:65]).all()
+    assert (ch[clear] == rows[clear, 34]).all()
+    fl = _np(env.flags())
+    assert ((fl & 1) == rows[:, 35])[clear].all()
+
+
+def test_epsilon_greedy_explores(bg, weights):
+    n = 4096
+    a, b = bg.VecGame(n, seed=5), bg.VecGame(n, seed=5)
+    a.load_weights(weights); b.load_weights(weights)
+    a.step_greedy(epsilon=0.0); b.step_greedy(epsilon=0.5)
+    ca, cb = _np(a.last_choice()["chosen"]), _np(b.last_choice()["chosen"])
+    frac = (ca != cb).mean()
+    assert 0.15 < frac < 0.55          # about half explore, some explorations hit the greedy index
+
+
+# ---- scalar Game surface (the reference's own tests, run through the drop-in module) ---------------------
+
+def test_scalar_game_known_answers(bg):
+    p1, p2 = bg.Player("A", bg.PlayerType.PLAYER1), bg.Player("B", bg.PlayerType.PLAYER2)
+    g = bg.Game(0)
+    g.setPlayers(p1, p2)
+    assert g.getTurn() == bg.PlayerType.PLAYER1 and bg.Game(3).getTurn() == 1
+    assert g.getGameBoard() == START
+    assert g.legalMoves(bg.PlayerType.PLAYER1, 1) == [(1, 2), (17, 18), (19, 20)]          # tests.cpp:287
+    assert g.legalMoves(bg.PlayerType.PLAYER2, 1) == [(6, 5), (8, 7), (24, 23)]            # :300
+    assert g.legalMoves(0, 5) == [(12, 17), (17, 22)]                                      # :313
+    seqs = g.legalTurnSequences(0, 1, 2)
+    assert [(1, 2), (2, 4)] in seqs and [(1, 3), (3, 4)] in seqs and len(seqs) == 30       # :346
+    d = g.legalTurnSequences(0, 1, 1)
+    assert len(d) == 245 and all(len(q) == 4 for q in d) and [(19, 20)] * 4 in d           # :367
+    assert g.getGameBoard() == START                                                       # :390
+    assert g.tryMove(p1, 5, 1, 6) == (False, "Invalid destination.")                       # :116-121
+    seqs, states = g.evaluateTurnSequences(0, 3, 1)
+    assert states.shape == (len(seqs), 28) and states.dtype == np.int32
+    g.setGameBoard([-1] + [0] * 23)                                                        # :433-488
+    assert g.legalTurnSequences(1, 3, 2) == [[(1, 0)], [(1, 0)]]
+    assert g.legalTurnSequences(1, 1, 1) == [[(1, 0)]]
+    g.setBorneOffPieces(1, 14)
+    assert g.is_game_over() == (False, -1)
+    assert g.tryMove(p2, 1, 1, 0) == (True, "")
+    assert g.is_game_over() == (True, 1) and g.getBornOffCount(1) == 15 and g.getPieces().numFreed(1) == 15
+    with pytest.raises(TypeError):
+        bg.Player("x", 0)
+    c = g.clone()
+    assert c.getGameBoard() == g.getGameBoard() and c.get_last_dice() == [1, 1]
+    r = g.roll_dice()
+    assert len(r) == 2 and all(1 <= v <= 6 for v in r) and g.get_last_dice() == r
+    assert any(g.roll_dice() != r for _ in range(8))                                       # fresh dice per call
+
+
+def test_scalar_make_move_like_reference_tests(bg, weights):
+    """pysrc/tests.py:38-49 through the mirror classes, plus agreement with VecGame on the same board."""
+    from backgammon_env.policy import TDLGammonModel
+    m = TDLGammonModel()
+    m.load_flat(weights)
+    m.eval()
+    g = bg.Game(0)
+    p1, p2 = bg.Player("White", bg.PlayerType.PLAYER1), bg.Player("Black", bg.PlayerType.PLAYER2)
+    g.setPlayers(p1, p2)
+    g.setTurn(bg.PlayerType.PLAYER1)
+    g.setDice(3, 1)
+    seq = m.make_move(g)
+    assert seq == [(17, 20), (19, 20)]            # the reference's own choice for (3,1) from the start
+    assert g.getTurn() == 0                       # make_move does not flip the turn
+    b = g.getGameBoard()
+    assert b[16] == 2 and b[18] == 4 and b[19] == 2
+    x = m.encode_state_np(g)
+    assert x.shape == (198,) and x[192] == 1.0 and x[193] == 0.0
