@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play env steps/sec @65 536 concurrent games per MI355X (BASELINE.json metric).
+
+A "step" is one batched env step: every live lane rolls, enumerates its legal turn sequences,
+scores every afterstate with the 198->128->1 value net, applies the arg-max/arg-min and
+auto-resets finished games (config 3 of BASELINE.json, weights tdgammonNEW100k -- SURVEY.md
+explains why not bestModel.pth).  value = env steps (live-lane turns) of ALL ranks / wall time
+of the slowest rank, states resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "backgammon-engine_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GAMES_PER_GPU = 65536
+SEED = 20240603
+FLOP_PER_ROW = 2 * 198 * 128 + 2 * 128          # 50 944, SURVEY.md §8d
+PEAK = {"f32": 157.3, "hbm": 8000.0}            # TFLOP/s dense fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(weights, budget_s=12.0):
+    """Same workload on the host, bounded sample, ONE thread: the oracle port (greedy, fp32), and --
+    when the prebuilt reference engine travelled with the snapshot -- the unmodified reference's
+    evaluateTurnSequences loop (its move-gen, 84 % of its turn; its Python policy cannot travel)."""
+    from oracle import oracle as O
+    torch.set_num_threads(1)
+    lane, steps, t0 = None, 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, _, _, lane = O.lane_run(SEED, 0, GAMES_PER_GPU, 400, 1, weights=weights, lane=lane, want_snap=False)
+        steps += 400
+    dt = time.perf_counter() - t0
+    out = {"value": round(steps / dt, 1), "unit": "env steps/s", "cores": 1, "kind": "port",
+           "sample": f"{steps} greedy fp32 env steps of lane 0 (auto-reset, same Philox streams, same weights), "
+                     f"{dt:.1f} s, oracle/bg_oracle.c single thread"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+        import importlib
+        ref = importlib.import_module("backgammon_env_ref_probe") if False else None  # noqa: F841
+        import importlib.util
+        so = [f for f in os.listdir(os.path.join(ROOT, "oracle", "_ref")) if f.startswith("backgammon_env")]
+        spec = importlib.util.spec_from_file_location("backgammon_env", os.path.join(ROOT, "oracle", "_ref", so[0]))
+        rb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rb)
+        p1, p2 = rb.Player("a", rb.PlayerType.PLAYER1), rb.Player("b", rb.PlayerType.PLAYER2)
+        n, t0, gid = 0, time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s * 0.5:
+            g = rb.Game(0); g.setPlayers(p1, p2)
+            g.setTurn(O.lib().bgo_opening_turn(SEED, gid))
+            ply = 0
+            while time.perf_counter() - t0 < budget_s * 0.5:
+                d1, d2, cu, _ = O.turn_randoms(SEED, gid, ply)
+                t = g.getTurn()
+                seqs, _ = g.evaluateTurnSequences(t, d1, d2)
+                if seqs:
+                    pl = g.getPlayers(t)
+                    for o, d in seqs[(cu * len(seqs)) >> 32]:
+                        g.tryMove(pl, abs(o - d), o, d)
+                n += 1
+                if g.is_game_over()[0]:
+                    break
+                g.setTurn(1 - t); ply += 1
+            gid += 1
+        dt = time.perf_counter() - t0
+        out["reference_engine"] = {"value": round(n / dt, 1), "unit": "env steps/s", "cores": 1, "kind": "reference",
+                                   "sample": f"{n} random-policy steps through the unmodified reference's "
+                                             f"evaluateTurnSequences+tryMove (oracle/_ref, g++ -O2), {dt:.1f} s"}
+    except Exception as e:  # the prebuilt reference module is optional on the GPU box
+        out["reference_engine"] = {"value": None, "note": f"oracle/_ref not usable here: {type(e).__name__}"}
+    return out
+
+
+def distinct_ratio(env, sample_lanes=4096):
+    """U/C on the current boards: distinct afterstates / raw candidates over a lane sample."""
+    offs, cnts, st, _, _ = env.enumerate()
+    offs, cnts, st = offs.cpu().numpy(), cnts.cpu().numpy(), st.cpu().numpy()
+    u = c = 0
+    for lane in range(0, env.n, max(1, env.n // sample_lanes)):
+        k = int(cnts[lane])
+        if k:
+            u += len(np.unique(st[offs[lane]:offs[lane] + k], axis=0))
+            c += k
+    return (u / c) if c else 1.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
+    ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import backgammon_env as bg
+    from backgammon_env.shard import aggregate, shard_for_rank
+
+    w = np.fromfile(os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32"), dtype=np.float32)
+    off, stride = shard_for_rank(rank, world, a.games)
+    env = bg.VecGame(a.games, device=local_rank, seed=SEED, lane_offset=off, lane_stride=stride,
+                     arena_rows=a.games * 512)
+    env.load_weights(w)
+    for _ in range(a.burnin + a.warmup):
+        env.step_greedy()
+    torch.cuda.synchronize()
+    env.stats()                                   # raises on arena overflow
+    env.reset_stats()
+    if not a.no_kernel_timing:
+        env.time_kernels(True)
+        env.kernel_times()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        env.step_greedy()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    kt = env.kernel_times() if not a.no_kernel_timing else None
+    env.time_kernels(False)
+    st = env.stats()
+    tot, t_max = aggregate({k: st[k] for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated")},
+                           elapsed, device=dev)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ratio = distinct_ratio(env)
+    out = {
+        "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
+        "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
+                               "(tdgammonNEW100k weights), auto-reset, Philox dice",
+                   "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
+                   "candidates_per_step": round(tot["candidates_raw"] / max(tot["steps"], 1), 2),
+                   "distinct_over_raw": round(ratio, 4), "games_finished": tot["games_finished"]},
+    }
+    if kt:
+        per = {k: (v["ms"] / v["launches"] if v["launches"] else 0.0) for k, v in kt.items()}
+        rows_per_launch = st["rows_evaluated"] / max(kt["eval"]["launches"], 1)
+        steps_per_launch = st["steps"] / max(kt["emit"]["launches"], 1)
+        eval_tf = rows_per_launch * ratio * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+        emit_bytes = steps_per_launch * 52 + (st["candidates_raw"] / max(kt["emit"]["launches"], 1)) * 36
+        emit_gbs = emit_bytes / (per["emit"] * 1e-3) / 1e9 if per["emit"] else 0.0
+        roof_eval = {"kernel": "eval_rows_f32_kernel", "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK["f32"],
+                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK["f32"], 4), "traffic": None,
+                     "avg_ms": round(per["eval"], 4),
+                     "note": "algorithmic flops = distinct afterstates x 50 944; the kernel currently evaluates the raw "
+                             "list (rows_evaluated/launch = %d)" % rows_per_launch}
+        roof_emit = {"kernel": "emit_kernel", "bound": "hbm", "achieved": round(emit_gbs, 2), "peak": PEAK["hbm"],
+                     "unit": "GB/s", "frac": round(emit_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["emit"], 4)}
+        dominant = roof_eval if per["eval"] >= per["emit"] else roof_emit
+        out["roofline"] = dominant
+        out["kernels"] = {"eval": roof_eval, "emit": roof_emit, "select_apply_avg_ms": round(per["select_apply"], 4),
+                          "gpu_ms_per_step": round(sum(per.values()), 4)}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
