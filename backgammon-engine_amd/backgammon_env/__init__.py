@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import AUTO_RESET, BF16, F32, NO_FLIP, ROLL, BgamdError  # noqa: F401
+from ._capi import AUTO_RESET, BF16, F32, NO_FLIP, ROLL, WANT_INDEX, BgamdError  # noqa: F401
 
 __all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed"]
 
@@ -200,8 +200,10 @@ class VecGame:
         if c is not None:
             torch.cuda.current_stream().synchronize()
 
-    def step_greedy(self, roll=True, auto_reset=True, epsilon=0.0, precision=F32, no_flip=False):
-        _capi.check(self._lib.bgamd_env_step_greedy(self._h, self._flags(roll, auto_reset, no_flip), float(epsilon),
+    def step_greedy(self, roll=True, auto_reset=True, epsilon=0.0, precision=F32, no_flip=False, want_index=False):
+        """want_index: also report the chosen reference-order index and the list length (slow path)."""
+        _capi.check(self._lib.bgamd_env_step_greedy(self._h, self._flags(roll, auto_reset, no_flip) |
+                                                    (WANT_INDEX if want_index else 0), float(epsilon),
                                                     int(precision), _stream()), "step_greedy")
 
     def last_choice(self):
@@ -213,9 +215,10 @@ class VecGame:
         return {"chosen": ch, "count": cnt, "seq": sq, "seq_len": ln, "value": val}
 
     def stats(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         _capi.check(self._lib.bgamd_env_stats(self._h, out), "stats")
-        k = ("steps", "games_finished", "p1_wins", "candidates_raw", "rows_evaluated", "error_flags")
+        k = ("steps", "games_finished", "p1_wins", "candidates_raw", "rows_evaluated", "error_flags",
+             "leaf_parent_nodes", "doubles_inner_nodes")
         return dict(zip(k, [int(v) for v in out]))
 
     def reset_stats(self):
@@ -261,9 +264,9 @@ class VecGame:
         _capi.check(self._lib.bgamd_env_time_kernels(self._h, int(enable)), "time_kernels")
 
     def kernel_times(self):
-        ms, n = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        ms, n = (C.c_double * 8)(), (C.c_uint64 * 8)()
         _capi.check(self._lib.bgamd_env_kernel_times(self._h, ms, n), "kernel_times")
-        names = ("emit", "eval", "select_apply", "step_random")
+        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves")
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
 
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbgamd.so")
 
 OK = 0
-ROLL, AUTO_RESET, NO_FLIP = 1, 2, 4
+ROLL, AUTO_RESET, NO_FLIP, WANT_INDEX = 1, 2, 4, 8
 F32, BF16 = 0, 1
 
 # every symbol include/bgamd.h declares: (name, restype, argtypes)

@@ -90,7 +90,8 @@ inline void relayout_w1_f32(const float *w1 /*[128][198]*/, float *wl /*[99][64]
 __global__ __launch_bounds__(256) void eval_rows_f32_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wl, const float *__restrict__ b1, const float *__restrict__ w2,
-    const float *__restrict__ b2p, float *__restrict__ values)
+    const float *__restrict__ b2p, float *__restrict__ values, const uint2 *__restrict__ info,
+    unsigned long long *__restrict__ best)
 {
     extern __shared__ float4 sW[];
     for (int i = threadIdx.x; i < K_STEPS * 64; i += 256) sW[i] = wl[i];
@@ -163,7 +164,18 @@ __global__ __launch_bounds__(256) void eval_rows_f32_kernel(
         for (int j = 1; j < 16; ++j) mine = (r == j) ? part[j] : mine;
         if (r < 16) {
             const long long orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (orow < n_rows) values[orow] = fast_sigmoid(mine + b2);
+            if (orow < n_rows) {
+                const float v = fast_sigmoid(mine + b2);
+                values[orow] = v;
+                if (info) {
+                    // per-game arg-max (P1) / arg-min (P2) with "smallest reference key wins ties":
+                    // one 64-bit atomicMax of (ordered value bits, ~key)      (model.py:212-213)
+                    const uint2 inf = info[orow];
+                    uint32_t bits = __float_as_uint(v);
+                    bits = (inf.y >> 31) ? ~bits : bits;
+                    atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
+                }
+            }
         }
     }
 }

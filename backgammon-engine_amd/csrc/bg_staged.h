@@ -1,0 +1,91 @@
+// bg_staged.h -- load-balanced greedy step: the turn-sequence tree of every game is expanded one
+// ply per kernel ("node" = game + move prefix), so no lane ever walks more than one node:
+//
+//   roots_kernel    lane per game : roll, first-ply moves      -> D1 (doubles) / F (leaf parents)
+//   expand_kernel   lane per node : doubles ply 2 and 3        -> D2 / F
+//   leaves_kernel   lane per F node: <= 15 afterstates each, staged per workgroup, de-duplicated
+//                   through an LDS hash (exact 256-bit compare)  -> unique rows + (game, key)
+//   eval kernel     (bg_eval.h)   : value per unique row, atomicMax of (value, ~key) per game
+//   apply_kernel    lane per game : decode the winning key, replay its <= 4 moves, terminal/reset
+//
+// Reference order is carried by the KEY instead of by position: key = pass | o0 | o1 | o2 | o3 | len
+// compares exactly like the index into legalTurnSequences' list (cppsrc/game.cpp:134-191: d1-first
+// block then d2-first block, ascending origins, DFS pre-order for doubles), so "first index wins
+// ties" (model.py:212-213) is "smallest key wins" and duplicates can be dropped anywhere.
+#pragma once
+#include "bg_board.h"
+
+namespace bg {
+
+// key layout (bit 31 is used for the mover's turn inside row info only)
+constexpr int KEY_PASS_SHIFT = 23;
+__host__ __device__ __forceinline__ int key_len(uint32_t k) { return (int)(k & 7u); }
+__host__ __device__ __forceinline__ int key_pass(uint32_t k) { return (int)((k >> KEY_PASS_SHIFT) & 1u); }
+__host__ __device__ __forceinline__ int key_origin(uint32_t k, int i) { return (int)((k >> (18 - 5 * i)) & 31u); }
+__host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
+{
+    const int len = key_len(k);
+    return (k & ~7u) | ((uint32_t)o << (18 - 5 * len)) | (uint32_t)(len + 1);
+}
+
+struct Node { uint32_t game, key; };
+
+// ---- workgroup (256 threads) exclusive scan; returns the prefix, *total = sum over the block ----
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *s_wave /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();                       // s_wave may still be read by the previous scan
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t x = s_wave[w];
+        if (w < wv) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// bump allocation of `total` entries for the whole block (thread 0 does the atomic)
+__device__ __forceinline__ unsigned long long block_alloc(unsigned long long *top, uint32_t total, unsigned long long *s_slot)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) *s_slot = total ? atomicAdd(top, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    return *s_slot;
+}
+
+struct StagedView {
+    Node *d1, *d2, *f;                    // node lists
+    long long cap_d1, cap_d2, cap_f;
+    uint4 *raw_rows;                      // per-workgroup staging of all leaves (2 x uint4 each)
+    uint2 *raw_info;                      // (game, key | turn<<31)
+    uint4 *u_rows;                        // unique rows
+    uint2 *u_info;
+    long long cap_rows;
+    unsigned long long *best;             // [n] (ordered value bits << 32) | ~key ; 0 = no candidate
+    unsigned long long *tops;             // [T_COUNT]
+};
+enum { T_D1 = 0, T_D2, T_F, T_RAW, T_U, T_COUNT };
+
+__device__ __forceinline__ uint32_t hash_row(const uint32_t (&p)[8], uint32_t game)
+{
+    uint32_t h = game * 0x9E3779B1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h ^= p[k];
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 15;
+    }
+    return h;
+}
+
+}  // namespace bg

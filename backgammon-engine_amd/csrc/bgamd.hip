@@ -17,12 +17,13 @@
 #include "bg_board.h"
 #include "bg_eval.h"
 #include "bg_movegen.h"
+#include "bg_staged.h"
 
 using namespace bg;
 
 namespace {
 
-enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_SCRATCH, C_COUNT };
+enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_FNODES, C_DNODES, C_COUNT };
 enum { ERRF_ARENA = 1, ERRF_STATE = 2 };
 constexpr uint32_t META_FINISHED = 1u << 12;
 
@@ -539,6 +540,8 @@ __global__ void legal_moves_kernel(EnvView e, const int32_t *__restrict__ player
     n_out[g] = n;
 }
 
+#include "bg_staged_kernels.h"
+
 // marks the mover's direction in the packed sequences of the last step (bit 29) -- see unpack_seq
 __global__ void tag_chosen_seq_kernel(EnvView e, const uint32_t *__restrict__ turn_before)
 {
@@ -565,6 +568,7 @@ static thread_local std::string g_hip_err;
 struct bgamd_env {
     int device = 0;
     EnvView v{};
+    StagedView sv{};
     uint32_t *turn_before = nullptr;       // [n] mover of the last step
     float *d_w = nullptr;                  // raw weights 25601
     float4 *d_wl = nullptr;                // fp32 MFMA layout [99][64]
@@ -575,8 +579,8 @@ struct bgamd_env {
     std::vector<hipEvent_t> ev;            // pairs
     std::vector<int> ev_kind;
     size_t ev_used = 0;
-    double t_ms[4] = {0, 0, 0, 0};
-    uint64_t t_n[4] = {0, 0, 0, 0};
+    double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -678,6 +682,24 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     HIPCHK(hipMalloc(&v.counters, C_COUNT * 8));
     HIPCHK(hipMalloc(&env->d_w, N_PARAMS * 4));
     HIPCHK(hipMalloc(&env->d_wl, EVAL_LDS_BYTES));
+    {   // staged greedy step (bg_staged.h): node lists, per-workgroup staging, unique arena
+        StagedView &sv = env->sv;
+        const long long ng = n_games;
+        sv.cap_d1 = ng * 15 < 4096 ? 4096 : ng * 15;
+        sv.cap_d2 = ng * 64 < 4096 ? 4096 : ng * 64;
+        sv.cap_f = ng * 256 < 16384 ? 16384 : ng * 256;
+        sv.cap_rows = cap;
+        HIPCHK(hipMalloc(&sv.d1, (size_t)sv.cap_d1 * sizeof(Node)));
+        HIPCHK(hipMalloc(&sv.d2, (size_t)sv.cap_d2 * sizeof(Node)));
+        HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
+        sv.raw_rows = v.rows;                       // the ordered arena doubles as staging
+        HIPCHK(hipMalloc(&sv.raw_info, (size_t)cap * sizeof(uint2)));
+        HIPCHK(hipMalloc(&sv.u_rows, (size_t)cap * 32));
+        HIPCHK(hipMalloc(&sv.u_info, (size_t)cap * sizeof(uint2)));
+        HIPCHK(hipMalloc(&sv.best, n * 8));
+        HIPCHK(hipMalloc(&sv.tops, T_COUNT * 8));
+        HIPCHK(hipMemset(sv.tops, 0, T_COUNT * 8));
+    }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_BYTES));
     *out = env;
@@ -691,7 +713,8 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl};
+                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl,
+                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
     delete env;
@@ -842,7 +865,7 @@ int bgamd_env_load_weights(bgamd_env *env, const float *h_weights)
 }
 
 static int launch_eval(bgamd_env *env, int precision, const unsigned long long *n_rows_ptr, long long n_rows_imm,
-                       const uint4 *rows, float *values, hipStream_t s)
+                       const uint4 *rows, float *values, const uint2 *info, unsigned long long *best, hipStream_t s)
 {
     if (precision != BGAMD_F32) return BGAMD_E_INVALID;     // bf16 path: later round
     const float *b1 = env->d_w + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
@@ -850,7 +873,7 @@ static int launch_eval(bgamd_env *env, int precision, const unsigned long long *
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(256), EVAL_LDS_BYTES, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
-                           (const float4 *)env->d_wl, b1, w2, b2, values);
+                           (const float4 *)env->d_wl, b1, w2, b2, values, info, best);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -863,15 +886,32 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     hipStream_t s = (hipStream_t)stream;
     int rc = snapshot_turn(env, s);
     if (rc) return rc;
-    rc = launch_emit(env, flags, 1, nullptr, nullptr, s);
-    if (rc) return rc;
-    rc = launch_eval(env, precision, &env->v.counters[C_ARENA_TOP], 0, env->v.rows, env->v.values, s);
+    StagedView &sv = env->sv;
+    const long long n = env->v.n;
+    HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
+    const unsigned per_cu = 4;
+    auto pgrid = [&](long long max_items) {
+        long long b = (max_items + 255) / 256;
+        const long long lim = (long long)env->n_cu * per_cu;
+        return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
+    };
+    {
+        KTimer t(env, s, 4);
+        hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
+        hipLaunchKernelGGL(expand_kernel<1>, pgrid(n * 15), dim3(256), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<2>, pgrid(n * 225), dim3(256), 0, s, env->v, sv);
+    }
+    {
+        KTimer t(env, s, 5);
+        hipLaunchKernelGGL(leaves_kernel, pgrid(n * 3375), dim3(256), 0, s, env->v, sv);
+    }
+    rc = launch_eval(env, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
     if (rc) return rc;
     {
         KTimer t(env, s, 2);
-        hipLaunchKernelGGL(select_apply_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, epsilon, 1);
+        hipLaunchKernelGGL(apply_kernel, grid1(n, 64), dim3(64), 0, s, env->v, sv, flags, epsilon);
     }
-    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, env->turn_before);
+    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->turn_before);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -886,7 +926,7 @@ int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, i
     return BGAMD_OK;
 }
 
-int bgamd_env_stats(bgamd_env *env, uint64_t h_out[6])
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[8])
 {
     if (!env || !h_out) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(env->device));
@@ -895,6 +935,7 @@ int bgamd_env_stats(bgamd_env *env, uint64_t h_out[6])
     HIPCHK(hipMemcpy(h, env->v.counters, sizeof h, hipMemcpyDeviceToHost));
     h_out[0] = h[C_STEPS]; h_out[1] = h[C_FINISHED]; h_out[2] = h[C_P1WINS];
     h_out[3] = h[C_CAND_RAW]; h_out[4] = h[C_ROWS_EVAL]; h_out[5] = h[C_ERR];
+    h_out[6] = h[C_FNODES]; h_out[7] = h[C_DNODES];
     return check_err_flags(env, h[C_ERR]);
 }
 
@@ -945,7 +986,7 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
     // the candidate arena doubles as scratch for caller-provided states
     hipLaunchKernelGGL(pack_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_turn, (long long)n, env->v.rows,
                        &env->v.counters[C_ERR]);
-    return launch_eval(env, precision, nullptr, (long long)n, env->v.rows, d_values, s);
+    return launch_eval(env, precision, nullptr, (long long)n, env->v.rows, d_values, nullptr, nullptr, s);
 }
 
 int bgamd_env_time_kernels(bgamd_env *env, int enable)
@@ -956,12 +997,12 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
     return BGAMD_OK;
 }
 
-int bgamd_env_kernel_times(bgamd_env *env, double h_ms[4], uint64_t h_launches[4])
+int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8])
 {
     if (!env) return BGAMD_E_INVALID;
     const int rc = flush_events(env);
     if (rc) return rc;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         if (h_ms) h_ms[i] = env->t_ms[i];
         if (h_launches) h_launches[i] = env->t_n[i];
         env->t_ms[i] = 0; env->t_n[i] = 0;

@@ -168,23 +168,30 @@ def main():
                    "distinct_over_raw": round(ratio, 4), "games_finished": tot["games_finished"]},
     }
     if kt:
+        nl = max(kt["eval"]["launches"], 1)
         per = {k: (v["ms"] / v["launches"] if v["launches"] else 0.0) for k, v in kt.items()}
-        rows_per_launch = st["rows_evaluated"] / max(kt["eval"]["launches"], 1)
-        steps_per_launch = st["steps"] / max(kt["emit"]["launches"], 1)
-        eval_tf = rows_per_launch * ratio * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
-        emit_bytes = steps_per_launch * 52 + (st["candidates_raw"] / max(kt["emit"]["launches"], 1)) * 36
-        emit_gbs = emit_bytes / (per["emit"] * 1e-3) / 1e9 if per["emit"] else 0.0
-        roof_eval = {"kernel": "eval_rows_f32_kernel", "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK["f32"],
-                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK["f32"], 4), "traffic": None,
-                     "avg_ms": round(per["eval"], 4),
-                     "note": "algorithmic flops = distinct afterstates x 50 944; the kernel currently evaluates the raw "
-                             "list (rows_evaluated/launch = %d)" % rows_per_launch}
-        roof_emit = {"kernel": "emit_kernel", "bound": "hbm", "achieved": round(emit_gbs, 2), "peak": PEAK["hbm"],
-                     "unit": "GB/s", "frac": round(emit_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["emit"], 4)}
-        dominant = roof_eval if per["eval"] >= per["emit"] else roof_emit
-        out["roofline"] = dominant
-        out["kernels"] = {"eval": roof_eval, "emit": roof_emit, "select_apply_avg_ms": round(per["select_apply"], 4),
-                          "gpu_ms_per_step": round(sum(per.values()), 4)}
+        rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
+        fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
+        u_l = raw_l * ratio                                    # distinct afterstates per launch (sampled ratio)
+        eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+        # algorithmic bytes: leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
+        # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
+        leaves_gbs = (fn_l * 52 + u_l * 40) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
+        expand_gbs = (steps_l * 52 + (fn_l + 2 * dn_l) * 8 + dn_l * 44) / (per["expand"] * 1e-3) / 1e9 if per["expand"] else 0.0
+        roofs = {
+            "eval": {"kernel": "eval_rows_f32_kernel", "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK["f32"],
+                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK["f32"], 4), "traffic": None, "avg_ms": round(per["eval"], 4),
+                     "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)},
+            "leaves": {"kernel": "leaves_kernel", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
+                       "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
+            "expand": {"kernel": "roots_kernel+expand_kernel<1,2>", "bound": "hbm", "achieved": round(expand_gbs, 2),
+                       "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
+                       "avg_ms": round(per["expand"], 4)},
+        }
+        dom = max(roofs, key=lambda k: roofs[k]["avg_ms"])
+        out["roofline"] = roofs[dom]
+        out["kernels"] = dict(roofs, apply_avg_ms=round(per["apply"], 4),
+                              gpu_ms_per_step=round(per["eval"] + per["leaves"] + per["expand"] + per["apply"], 4))
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)

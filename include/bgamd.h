@@ -44,8 +44,11 @@ enum {
                                  bgamd_env_set_dice are used (Game::setDice, game.cpp:9-12)     */
     BGAMD_AUTO_RESET = 2,     /* a finished game restarts (new episode, opening roll);
                                  without it a finished game stays finished and is skipped      */
-    BGAMD_NO_FLIP = 4         /* do not flip the turn / advance ply (make_move semantics,
+    BGAMD_NO_FLIP = 4,        /* do not flip the turn / advance ply (make_move semantics,
                                  model.py:180-222, for the scalar Game surface)                */
+    BGAMD_WANT_INDEX = 8      /* greedy step: also report the chosen move's index into the
+                                 reference-order list and the list length (walks the whole list
+                                 per lane: parity/debug use, not the throughput path)           */
 };
 
 enum { BGAMD_F32 = 0, BGAMD_BF16 = 1 };   /* value-net arithmetic */
@@ -105,8 +108,9 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
  *   greedy: TDLGammonModel.make_move (model.py:180-222): value net on every afterstate with the
  *           MOVER's turn bit, argmax (P1) / argmin (P2), first index wins ties; epsilon > 0 draws
  *           the exploration test and index from the TURN stream.  precision BGAMD_F32 | BGAMD_BF16.
- * Per-lane results of the last step: chosen reference-order index (-1 = no move), packed sequence,
- * candidate count, value of the chosen afterstate. */
+ * Per-lane results of the last step: chosen reference-order index (-1 = no move), sequence, candidate
+ * count, value of the chosen afterstate.  The greedy step reports index and count exactly only with
+ * BGAMD_WANT_INDEX; without it index is 0 and count 1 when a move was made (-1 / 0 when none was). */
 int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
 int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);
@@ -114,8 +118,8 @@ int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, i
                           int32_t *d_seq_len, float *d_value, void *stream);
 
 /* counters since create/reset_stats (synchronises): [steps, games_finished, p1_wins, candidates_raw,
- * rows_evaluated, error_flags] */
-int bgamd_env_stats(bgamd_env *env, uint64_t h_out[6]);
+ * rows_evaluated, error_flags, leaf_parent_nodes, doubles_inner_nodes] */
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[8]);
 int bgamd_env_reset_stats(bgamd_env *env, void *stream);
 
 /* single-checker surface for lane-wise moves: Game::tryMove (game.cpp:573-663) and
@@ -131,11 +135,12 @@ int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, fl
 int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, int64_t n,
                    int precision, float *d_values, void *stream);
 
-/* kernel timing hook for bench.py: brackets the value-net kernel of each greedy step with HIP
- * events on `stream`; bgamd_env_eval_time_ms returns the accumulated milliseconds and launch
- * count since the last call (synchronises). */
+/* kernel timing hook for bench.py: brackets kernel groups with HIP events on the launch stream;
+ * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
+ * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
+ * 4 roots+expand (plies 1-3), 5 leaves+dedup. */
 int bgamd_env_time_kernels(bgamd_env *env, int enable);
-int bgamd_env_kernel_times(bgamd_env *env, double h_ms[4], uint64_t h_launches[4]);
+int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8]);
 
 #ifdef __cplusplus
 }

@@ -270,7 +270,7 @@ def test_g5_reference_greedy_games(bg, golden_dir, weights):
     env.load_weights(weights)
     env.set_states(rows[:, 2:30], rows[:, 30])
     env.set_dice(rows[:, 31:33])
-    env.step_greedy(roll=False, auto_reset=False)
+    env.step_greedy(roll=False, auto_reset=False, want_index=True)
     post = _np(env.states())
     lc = env.last_choice()
     ch, cn = _np(lc["chosen"]), _np(lc["count"])
@@ -281,6 +281,35 @@ def test_g5_reference_greedy_games(bg, golden_dir, weights):
     assert (ch[clear] == rows[clear, 34]).all()
     fl = _np(env.flags())
     assert ((fl & 1) == rows[:, 35])[clear].all()
+
+
+def test_greedy_index_matches_ordered_enumeration(bg, weights):
+    """The staged greedy step (keys, de-duplicated rows) against the env's own ordered enumeration:
+    with BGAMD_WANT_INDEX the reported index points at the applied afterstate in the reference-order
+    list, the reported sequence is that entry's sequence, and it is the FIRST entry with that board."""
+    n = 4096
+    env = bg.VecGame(n, seed=99, arena_rows=4 << 20)
+    env.load_weights(weights)
+    for _ in range(25):
+        env.step_greedy()
+    env.roll()
+    offs, cnts, st, sq, ln = [_np(x) for x in env.enumerate()]
+    env.step_greedy(roll=False, auto_reset=False, want_index=True)
+    post = _np(env.states())
+    lc = env.last_choice()
+    ch, cn, cs, cl = _np(lc["chosen"]), _np(lc["count"]), _np(lc["seq"]), _np(lc["seq_len"])
+    assert (cn == cnts).all()
+    for lane in range(n):
+        if cnts[lane] == 0:
+            assert ch[lane] == -1
+            continue
+        r = int(offs[lane]) + int(ch[lane])
+        assert (st[r] == post[lane]).all(), lane
+        assert (sq[r] == cs[lane]).all() and ln[r] == cl[lane], lane
+        seg = st[int(offs[lane]):r]
+        assert not (seg == post[lane]).all(1).any(), lane       # first occurrence
+    s = env.stats()
+    assert s["rows_evaluated"] < 0.5 * s["candidates_raw"]      # duplicates were dropped before the value net
 
 
 def test_epsilon_greedy_explores(bg, weights):
