@@ -217,6 +217,7 @@ def test_values_vs_reference_model(bg, O, golden_dir, weights):
     env = bg.VecGame(1, arena_rows=1 << 20)
     env.load_weights(weights)
     v = _np(env.evaluate(g["states"].astype(np.int32), g["turn"]))
+    print("max |gpu - torch fp32| = %.3g, max |gpu - torch fp64| = %.3g" % (np.abs(v - g["v32"]).max(), np.abs(v - g["v64"]).max()))
     assert np.abs(v - g["v32"]).max() < 1e-5
     assert np.abs(v - g["v64"]).max() < 1e-5
     # ragged sizes around the 32-row tile, and a large batch
