@@ -20,6 +20,7 @@ constexpr int N_IN = 198, N_HID = 128;
 constexpr int N_PARAMS = N_HID * N_IN + N_HID + N_HID + 1;
 constexpr int K_STEPS = N_IN / 2;                  // 99
 constexpr int EVAL_LDS_BYTES = K_STEPS * 64 * 16;  // 101 376
+constexpr int EVAL_THREADS = 512;                  // 8 waves per CU: two per SIMD share the MFMA pipe and hide each other's stalls
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -87,14 +88,19 @@ inline void relayout_w1_f32(const float *w1 /*[128][198]*/, float *wl /*[99][64]
 }
 
 // rows: 2 x uint4 per candidate.  n_rows_ptr: device counter (rows emitted this step), or null -> n_rows_imm.
-__global__ __launch_bounds__(256) void eval_rows_f32_kernel(
+constexpr int EVAL_RED_STRIDE = 33;                                   // floats per column in the reduction scratch
+constexpr int EVAL_RED_FLOATS = 32 * EVAL_RED_STRIDE;                 // per wave
+constexpr int EVAL_LDS_TOTAL = EVAL_LDS_BYTES + (EVAL_THREADS / 64) * EVAL_RED_FLOATS * 4;
+
+__global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wl, const float *__restrict__ b1, const float *__restrict__ w2,
     const float *__restrict__ b2p, float *__restrict__ values, const uint2 *__restrict__ info,
     unsigned long long *__restrict__ best)
 {
     extern __shared__ float4 sW[];
-    for (int i = threadIdx.x; i < K_STEPS * 64; i += 256) sW[i] = wl[i];
+    float *sRed = reinterpret_cast<float *>(sW + K_STEPS * 64) + (threadIdx.x >> 6) * EVAL_RED_FLOATS;
+    for (int i = threadIdx.x; i < K_STEPS * 64; i += EVAL_THREADS) sW[i] = wl[i];
     __syncthreads();
 
     const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
@@ -102,70 +108,102 @@ __global__ __launch_bounds__(256) void eval_rows_f32_kernel(
     const long long n_tiles = (n_rows + 31) >> 5;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long n_waves = (long long)gridDim.x * 4;
+    const long long wave = (long long)blockIdx.x * (EVAL_THREADS / 64) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (EVAL_THREADS / 64);
 
-    float b1v[4], w2v[4];
+    // sigmoid(a + b1) = 1 / (1 + 2^(a*(-log2 e) + b1*(-log2 e)))
+    constexpr float NL2E = -1.44269504088896340736f;
+    float b1s[4], w2v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { b1v[c] = b1[32 * c + r]; w2v[c] = w2[32 * c + r]; }
+    for (int c = 0; c < 4; ++c) { b1s[c] = NL2E * b1[32 * c + r]; w2v[c] = w2[32 * c + r]; }
     const float b2 = *b2p;
 
+    // software pipeline: the next tile's row is in flight while this tile is in the MFMA loop
+    uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
+    if (wave < n_tiles && wave * 32 + r < n_rows) { nx0 = rows[2 * (wave * 32 + r)]; nx1 = rows[2 * (wave * 32 + r) + 1]; }
+
     for (long long tile = wave; tile < n_tiles; tile += n_waves) {
-        const long long row = tile * 32 + r;
-        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < n_rows) {
-            const uint4 u0 = rows[2 * row], u1 = rows[2 * row + 1];
-            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w;
-            p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        const uint32_t p[8] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
+        {
+            const long long nrow = (tile + n_waves) * 32 + r;
+            nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0);
+            if (nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; }
         }
         RowDecode rd;
         decode_setup(p, h, rd);
 
         floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
-#define BG_MFMA4(aval, s)                                                            \
+#define BG_MFMA4(aval, WV)                                                          \
     {                                                                                \
-        const float4 w = sW[(s) * 64 + lane];                                        \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.x, acc0, 0, 0, 0);      \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.y, acc1, 0, 0, 0);      \
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.z, acc2, 0, 0, 0);      \
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), w.w, acc3, 0, 0, 0);      \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).x, acc0, 0, 0, 0);    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).y, acc1, 0, 0, 0);    \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).z, acc2, 0, 0, 0);    \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).w, acc3, 0, 0, 0);    \
     }
+        // two waves share each SIMD: the one in its MFMA loop must win issue arbitration over the one in
+        // its VALU-dense epilogue (priority beats age: MI355X_MICROARCH.md, two waves per SIMD, item 2)
+        __builtin_amdgcn_s_setprio(2);
+        // B operands (W1 from LDS) are fetched one point (4 k-steps, 1 024 MFMA cycles) ahead of use
+        const float4 *wp = sW + lane;
+        float4 wa = wp[0 * 64], wb = wp[1 * 64], wc = wp[2 * 64], wd = wp[3 * 64];
 #pragma unroll 2
         for (int i = 0; i < 24; ++i) {
             const float a0 = decode_even(rd, 0, i);
             const float a1 = decode_odd(rd, 0, i);
             const float a2 = decode_even(rd, 1, i);
             const float a3 = decode_odd(rd, 1, i);
-            BG_MFMA4(a0, 4 * i);
-            BG_MFMA4(a1, 4 * i + 1);
-            BG_MFMA4(a2, 4 * i + 2);
-            BG_MFMA4(a3, 4 * i + 3);
+            // steps 4i+4 .. 4i+7 (i == 23: steps 96..98 and a dummy in-range read)
+            const int nb = (4 * i + 4) * 64;
+            const float4 na = wp[nb], nbb = wp[nb + 64], nc = wp[nb + 128], nd = wp[i < 23 ? nb + 192 : nb + 128];
+            BG_MFMA4(a0, wa);
+            BG_MFMA4(a1, wb);
+            BG_MFMA4(a2, wc);
+            BG_MFMA4(a3, wd);
+            wa = na; wb = nbb; wc = nc; wd = nd;
+            // pin the schedule: the 4 LDS reads of the NEXT point first, then this point's 16 MFMAs with
+            // the decode VALU of the following k-step in their shadow (cdna_hip_programming.md T19)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        BG_MFMA4(rd.tail[0], 96);
-        BG_MFMA4(rd.tail[1], 97);
-        BG_MFMA4(rd.tail[2], 98);
+        BG_MFMA4(rd.tail[0], wa);
+        BG_MFMA4(rd.tail[1], wb);
+        BG_MFMA4(rd.tail[2], wc);
 #undef BG_MFMA4
 
-        // epilogue: hidden sigmoid, dot with W2 (this lane's 4 columns), 32-lane butterfly
+        // epilogue: hidden sigmoid and the dot with W2 over this lane's 4 columns ...
+        __builtin_amdgcn_s_setprio(0);
         float part[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            part[j] = w2v[0] * fast_sigmoid(acc0[j] + b1v[0]) + w2v[1] * fast_sigmoid(acc1[j] + b1v[1]) +
-                      w2v[2] * fast_sigmoid(acc2[j] + b1v[2]) + w2v[3] * fast_sigmoid(acc3[j] + b1v[3]);
+            const float s0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc0[j], NL2E, b1s[0])));
+            const float s1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc1[j], NL2E, b1s[1])));
+            const float s2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc2[j], NL2E, b1s[2])));
+            const float s3 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc3[j], NL2E, b1s[3])));
+            part[j] = w2v[0] * s0 + w2v[1] * s1 + w2v[2] * s2 + w2v[3] * s3;
         }
+        // ... then the sum over the 32 columns through a per-wave LDS transpose: lane (col r, half h)
+        // holds rows (j&3) + 8*(j>>2) + 4h; scratch is [col][row] with a 33-float column stride
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) part[j] += __shfl_xor(part[j], m, 64);
-        }
-        // lane (l & 31) == j < 16 stores accumulator register j of its half
-        float mine = part[0];
+            for (int j = 0; j < 4; ++j) sRed[r * EVAL_RED_STRIDE + 8 * q + 4 * h + j] = part[4 * q + j];
+        __builtin_amdgcn_wave_barrier();
+        // lane (row r, half h) adds columns 16h .. 16h+15 of its row, halves are combined by one swap
+        float sum = 0.0f;
 #pragma unroll
-        for (int j = 1; j < 16; ++j) mine = (r == j) ? part[j] : mine;
-        if (r < 16) {
-            const long long orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int c = 0; c < 16; ++c) sum += sRed[(16 * h + c) * EVAL_RED_STRIDE + r];
+        sum += __shfl_xor(sum, 32, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) {
+            const long long orow = tile * 32 + r;
             if (orow < n_rows) {
-                const float v = fast_sigmoid(mine + b2);
+                const float v = fast_sigmoid(sum + b2);
                 values[orow] = v;
                 if (info) {
                     // per-game arg-max (P1) / arg-min (P2) with "smallest reference key wins ties":

@@ -701,7 +701,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         HIPCHK(hipMemset(sv.tops, 0, T_COUNT * 8));
     }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
-    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
     *out = env;
     return bgamd_env_reset(env, nullptr);
 }
@@ -871,7 +871,7 @@ static int launch_eval(bgamd_env *env, int precision, const unsigned long long *
     const float *b1 = env->d_w + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
     {
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(256), EVAL_LDS_BYTES, s, rows, n_rows_ptr,
+        hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const float4 *)env->d_wl, b1, w2, b2, values, info, best);
     }
