@@ -30,8 +30,9 @@ __host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
 
 struct Node { uint32_t game, key; };
 
-// ---- workgroup (256 threads) exclusive scan; returns the prefix, *total = sum over the block ----
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *s_wave /*[4]*/)
+// ---- workgroup exclusive scan (NW waves); returns the prefix, *total = sum over the block ----
+template <int NW = 4>
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *s_wave /*[NW]*/)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -45,7 +46,7 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint32_t x = s_wave[w];
         if (w < wv) base += x;
         tot += x;

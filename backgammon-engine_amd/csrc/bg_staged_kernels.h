@@ -130,26 +130,22 @@ __global__ __launch_bounds__(256) void expand_kernel(EnvView e, StagedView sv)
     }
 }
 
-// ---- leaves: lane per leaf-parent, per-workgroup staging + exact de-duplication ----------------------
-constexpr int LEAF_T = 8192;               // hash slots (u32 staging index), >= 2 x 256 x 15
-constexpr int LEAF_MAX = 256 * 15;
+// ---- leaves: lane per leaf-parent, per-workgroup LDS staging + exact de-duplication ------------------
+// A block takes 256 leaf parents (<= 15 afterstates each).  Leaves are staged in LDS in rounds of at
+// most LEAF_CAP rows, de-duplicated through an LDS hash (slot = SMALLEST staging index among identical
+// (game, 256-bit row); inside a block staging order == reference order for rows of one game), and only
+// the representatives are written to HBM (u_rows / u_info).  Nothing else leaves the CU.
+constexpr int LEAF_THREADS = 512;          // leaf parents per block iteration
+constexpr int LEAF_CAP = 2048;             // staged rows per round (40 B each, SoA)
+constexpr int LEAF_T = 4096;               // hash slots
 constexpr uint32_t LEAF_EMPTY = 0xFFFFFFFFu;
 
-__device__ __forceinline__ void write_leaf(const StagedView &sv, unsigned long long r, const Side &own, const Side &opp,
-                                           int pl, uint32_t game, uint32_t key)
+__global__ __launch_bounds__(LEAF_THREADS) void leaves_kernel(EnvView e, StagedView sv)
 {
-    const Side &s1 = pl ? opp : own;       // PLAYER1 planes
-    const Side &s2 = pl ? own : opp;
-    sv.raw_rows[2 * r] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
-    sv.raw_rows[2 * r + 1] = make_uint4(s2.b[0], s2.b[1], s2.b[2], s2.b[3]);
-    sv.raw_info[r] = make_uint2(game, key | (pl ? 0x80000000u : 0u));
-}
-
-__global__ __launch_bounds__(256) void leaves_kernel(EnvView e, StagedView sv)
-{
+    __shared__ uint32_t s_row[10][LEAF_CAP];   // p0..p7, game, key|turn<<31
     __shared__ uint32_t s_tab[LEAF_T];
-    __shared__ uint16_t s_pos[LEAF_MAX];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint16_t s_pos[LEAF_CAP];
+    __shared__ uint32_t s_wave[LEAF_THREADS / 64];
     __shared__ unsigned long long s_slot;
     unsigned long long n_in = sv.tops[T_F];
     if (n_in > (unsigned long long)sv.cap_f) n_in = (unsigned long long)sv.cap_f;
@@ -158,77 +154,86 @@ __global__ __launch_bounds__(256) void leaves_kernel(EnvView e, StagedView sv)
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
-    for (unsigned long long blk = blockIdx.x; blk * 256 < n_in; blk += gridDim.x) {
-        const unsigned long long ni = blk * 256 + threadIdx.x;
+    for (unsigned long long blk = blockIdx.x; blk * LEAF_THREADS < n_in; blk += gridDim.x) {
+        const unsigned long long ni = blk * LEAF_THREADS + threadIdx.x;
         const bool valid = ni < n_in;
         Node nd{0u, 0u};
         NodeState s;
-        uint32_t m = 0;
+        uint32_t m0 = 0;
         int die = 1;
         if (valid) {
             nd = sv.f[ni];
             node_state(e, nd, s);
             die = (s.len & 1) ? s.dB : s.dA;
-            if (s.len < (s.dbl ? 4 : 2)) m = legal_origins(s.own, s.opp, s.pl, die);
+            if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
         }
-        const uint32_t cnt = valid ? (m ? (uint32_t)__popc(m) : 1u) : 0u;
-        for (int i = threadIdx.x; i < LEAF_T; i += 256) s_tab[i] = LEAF_EMPTY;
+        const uint32_t cnt = valid ? (m0 ? (uint32_t)__popc(m0) : 1u) : 0u;
         uint32_t total;
-        uint32_t off = block_scan_256(cnt, &total, s_wave);
-        // Staging is written and re-read inside this block, through this CU's L1.  Regions are padded to
-        // 16 rows (512 B of rows, 128 B of info) so that no cache line is shared with another block's
-        // region: a co-resident block reading ITS rows would otherwise leave a stale copy of our
-        // not-yet-written rows in the shared L1.
-        const unsigned long long base = block_alloc(&sv.tops[T_RAW], (total + 15u) & ~15u, &s_slot);
-        if (base + total > (unsigned long long)sv.cap_rows) { flag_overflow(e); continue; }   // uniform over the block
+        const uint32_t off = block_scan_256<LEAF_THREADS / 64>(cnt, &total, s_wave);
         raw_total += total;
-        // 1. stage every leaf of this block, reference order inside a node
-        if (cnt) {
-            if (m == 0) write_leaf(sv, base + off, s.own, s.opp, s.pl, nd.game, nd.key);
-            else {
-                while (m) {
-                    const int o = __ffs(m) - 1; m &= m - 1;
-                    Side a = s.own, b = s.opp;
-                    apply_move(a, b, s.pl, o, die);
-                    write_leaf(sv, base + off++, a, b, s.pl, nd.game, key_child(nd.key, o));
+        const uint32_t info_turn = valid && s.pl ? 0x80000000u : 0u;
+        for (uint32_t r0 = 0; r0 < total; r0 += LEAF_CAP) {
+            const uint32_t nrow = total - r0 < (uint32_t)LEAF_CAP ? total - r0 : (uint32_t)LEAF_CAP;
+            for (int i = threadIdx.x; i < LEAF_T; i += LEAF_THREADS) s_tab[i] = LEAF_EMPTY;
+            // 1. stage this round's window [r0, r0 + nrow) of the block's leaves
+            if (cnt && off < r0 + nrow && off + cnt > r0) {
+                uint32_t m = m0, j = off;
+                do {
+                    int o = -1;
+                    if (m) { o = __ffs(m) - 1; m &= m - 1; }
+                    if (j >= r0 && j < r0 + nrow) {
+                        Side a = s.own, b = s.opp;
+                        uint32_t key = nd.key;
+                        if (o >= 0) { apply_move(a, b, s.pl, o, die); key = key_child(nd.key, o); }
+                        const Side &s1 = s.pl ? b : a, &s2 = s.pl ? a : b;
+                        const uint32_t q = j - r0;
+                        s_row[0][q] = s1.b[0] | (s.pl ? TURN_BIT : 0u); s_row[1][q] = s1.b[1];
+                        s_row[2][q] = s1.b[2]; s_row[3][q] = s1.b[3];
+                        s_row[4][q] = s2.b[0]; s_row[5][q] = s2.b[1]; s_row[6][q] = s2.b[2]; s_row[7][q] = s2.b[3];
+                        s_row[8][q] = nd.game; s_row[9][q] = key | info_turn;
+                    }
+                    ++j;
+                } while (m);
+            }
+            __syncthreads();
+            // 2. hash insert
+            for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) {
+                uint32_t p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p[k] = s_row[k][i];
+                const uint32_t game = s_row[8][i];
+                uint32_t h = hash_row(p, game) & (LEAF_T - 1);
+                for (;;) {
+                    const uint32_t cur = atomicCAS(&s_tab[h], LEAF_EMPTY, i);
+                    if (cur == LEAF_EMPTY) break;
+                    bool same = s_row[8][cur] == game;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) same = same && (s_row[k][cur] == p[k]);
+                    if (same) { atomicMin(&s_tab[h], i); break; }
+                    h = (h + 1) & (LEAF_T - 1);
+                }
+                s_pos[i] = (uint16_t)h;
+            }
+            __syncthreads();
+            // 3. representatives -> unique arena (order is irrelevant: the key carries it)
+            uint32_t mine = 0;
+            for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) mine += (s_tab[s_pos[i]] == i) ? 1u : 0u;
+            uint32_t tot2;
+            uint32_t off2 = block_scan_256<LEAF_THREADS / 64>(mine, &tot2, s_wave);
+            const unsigned long long base2 = block_alloc(&sv.tops[T_U], tot2, &s_slot);
+            const bool ok = base2 + tot2 <= (unsigned long long)sv.cap_rows;
+            if (!ok) flag_overflow(e);
+            if (ok) {
+                for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) {
+                    if (s_tab[s_pos[i]] != i) continue;
+                    const unsigned long long d = base2 + off2++;
+                    sv.u_rows[2 * d] = make_uint4(s_row[0][i], s_row[1][i], s_row[2][i], s_row[3][i]);
+                    sv.u_rows[2 * d + 1] = make_uint4(s_row[4][i], s_row[5][i], s_row[6][i], s_row[7][i]);
+                    sv.u_info[d] = make_uint2(s_row[8][i], s_row[9][i]);
                 }
             }
+            __syncthreads();                   // s_row / s_tab / s_pos are rewritten by the next round
         }
-        __syncthreads();                       // staging stores are complete (vmcnt(0) + barrier)
-        // 2. hash insert: slot keeps the SMALLEST staging index among identical (game, afterstate) rows;
-        //    inside a block, staging order == reference order for rows of one game
-        for (uint32_t i = threadIdx.x; i < total; i += 256) {
-            const uint4 a0 = sv.raw_rows[2 * (base + i)], a1 = sv.raw_rows[2 * (base + i) + 1];
-            const uint32_t game = sv.raw_info[base + i].x;
-            const uint32_t p[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            uint32_t h = hash_row(p, game) & (LEAF_T - 1);
-            for (;;) {
-                const uint32_t cur = atomicCAS(&s_tab[h], LEAF_EMPTY, i);
-                if (cur == LEAF_EMPTY) break;
-                const uint4 b0 = sv.raw_rows[2 * (base + cur)], b1 = sv.raw_rows[2 * (base + cur) + 1];
-                const bool same = sv.raw_info[base + cur].x == game && a0.x == b0.x && a0.y == b0.y && a0.z == b0.z &&
-                                  a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
-                if (same) { atomicMin(&s_tab[h], i); break; }
-                h = (h + 1) & (LEAF_T - 1);
-            }
-            s_pos[i] = (uint16_t)h;
-        }
-        __syncthreads();
-        // 3. compact the representatives into the unique arena
-        for (uint32_t c0 = 0; c0 < total; c0 += 256) {
-            const uint32_t i = c0 + threadIdx.x;
-            const bool uniq = i < total && s_tab[s_pos[i]] == i;
-            uint32_t tot2;
-            const uint32_t off2 = block_scan_256(uniq ? 1u : 0u, &tot2, s_wave);
-            const unsigned long long base2 = block_alloc(&sv.tops[T_U], tot2, &s_slot);
-            if (uniq) {
-                const unsigned long long d = base2 + off2;     // base2 + tot2 <= top(T_RAW) <= cap_rows
-                sv.u_rows[2 * d] = sv.raw_rows[2 * (base + i)];
-                sv.u_rows[2 * d + 1] = sv.raw_rows[2 * (base + i) + 1];
-                sv.u_info[d] = sv.raw_info[base + i];
-            }
-        }
-        __syncthreads();                       // s_tab / s_pos are rewritten by the next iteration
     }
     if (threadIdx.x == 0 && raw_total) atomicAdd(&e.counters[C_CAND_RAW], raw_total);
 }

@@ -903,7 +903,7 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     }
     {
         KTimer t(env, s, 5);
-        hipLaunchKernelGGL(leaves_kernel, pgrid(n * 3375), dim3(256), 0, s, env->v, sv);
+        hipLaunchKernelGGL(leaves_kernel, dim3(env->n_cu), dim3(LEAF_THREADS), 0, s, env->v, sv);
     }
     rc = launch_eval(env, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
     if (rc) return rc;
