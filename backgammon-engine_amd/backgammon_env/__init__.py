@@ -240,6 +240,30 @@ class VecGame:
         torch.cuda.current_stream().synchronize()
         return err
 
+    # -- trajectory log for the learner
+    def record_trajectory(self, max_plies: int | None):
+        """Allocates (or drops, with None) the per-turn log: int32 tensor [max_plies, n, 8] of 32-byte rows."""
+        if max_plies is None:
+            self._traj = None
+            _capi.check(self._lib.bgamd_env_set_trajectory(self._h, None, 0), "set_trajectory")
+            return None
+        self._traj = torch.zeros((int(max_plies), self.n, 8), dtype=torch.int32, device=self.device)
+        _capi.check(self._lib.bgamd_env_set_trajectory(self._h, _ptr(self._traj), int(max_plies)), "set_trajectory")
+        return self._traj
+
+    def progress(self):
+        ply, epi = self._buf((self.n,), torch.int32), self._buf((self.n,), torch.int32)
+        _capi.check(self._lib.bgamd_env_get_progress(self._h, _ptr(ply), _ptr(epi), _stream()), "get_progress")
+        return ply, epi
+
+    def encode_rows(self, rows):
+        """rows: int32 [..., 8] device tensor of 32-byte rows -> float32 [..., 198]."""
+        r = rows.contiguous()
+        n = r.numel() // 8
+        out = self._buf((n, 198), torch.float32)
+        _capi.check(self._lib.bgamd_encode_rows(_ptr(r), n, _ptr(out), _stream()), "encode_rows")
+        return out.reshape(*rows.shape[:-1], 198)
+
     # -- stateless operators on caller-provided states
     def encode(self, states28, turn):
         st = torch.as_tensor(states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)

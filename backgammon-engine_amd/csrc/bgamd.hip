@@ -40,6 +40,8 @@ struct EnvView {
     uint32_t *seqs;
     float *values;
     unsigned long long *counters;
+    uint4 *traj;               // optional [max_plies][n][2]: pre-move row of every turn (train.py:105-106)
+    long long traj_plies;
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int turn, int d1, int d2, bool fin)
@@ -962,6 +964,33 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
     if (!env || !d_player || !d_die || !d_n || !d_pairs) return BGAMD_E_INVALID;
     hipLaunchKernelGGL(legal_moves_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_player, d_die,
                        d_n, d_pairs);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies)
+{
+    if (!env || (d_rows && max_plies <= 0)) return BGAMD_E_INVALID;
+    env->v.traj = (uint4 *)d_rows;
+    env->v.traj_plies = d_rows ? max_plies : 0;
+    return BGAMD_OK;
+}
+
+int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (d_ply) HIPCHK(hipMemcpyAsync(d_ply, env->v.ply, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
+    if (d_episode) HIPCHK(hipMemcpyAsync(d_episode, env->v.episode, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
+    return BGAMD_OK;
+}
+
+int bgamd_encode_rows(const void *d_rows, int64_t n, float *d_out198, void *stream)
+{
+    if (!d_rows || !d_out198 || n < 0) return BGAMD_E_INVALID;
+    if (n == 0) return BGAMD_OK;
+    hipLaunchKernelGGL(encode_rows_kernel, grid1(n, 128), dim3(128), 0, (hipStream_t)stream, (const uint4 *)d_rows, (long long)n,
+                       d_out198);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }

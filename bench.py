@@ -188,6 +188,16 @@ def main():
                        "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
                        "avg_ms": round(per["expand"], 4)},
         }
+        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs; bench.py cannot
+        # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            for name, key in (("eval", "eval_rows_f32_kernel"), ("leaves", "leaves_kernel")):
+                if key in pmc:
+                    roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
+                    roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per launch)"
+        except Exception:
+            pass
         dom = max(roofs, key=lambda k: roofs[k]["avg_ms"])
         out["roofline"] = roofs[dom]
         out["kernels"] = dict(roofs, apply_avg_ms=round(per["apply"], 4),

@@ -129,6 +129,15 @@ int bgamd_env_try_move(bgamd_env *env, const int32_t *d_player, const int32_t *d
 int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t *d_die,
                           int32_t *d_n, int8_t *d_pairs /*[n,26,2]*/, void *stream);
 
+/* ---- trajectory log for the learner (the list of encodings play_game returns, train.py:105-106,
+ * kept as 32-byte rows: 8 bit planes, turn of the side to move in plane 0 bit 31).  When set, every
+ * greedy step stores the PRE-move row of each live lane at d_rows[(ply*n + lane)*32 B]; plies >=
+ * max_plies are dropped.  NULL disables.  bgamd_env_get_progress copies ply / episode per lane
+ * (a finished, frozen lane has ply = T-1).  bgamd_encode_rows: rows -> float[n][198]. */
+int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies);
+int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, void *stream);
+int bgamd_encode_rows(const void *d_rows, int64_t n, float *d_out198, void *stream);
+
 /* ---- stateless operators ----------------------------------------------------------------------
  * _encode_states_np (model.py:111-144) and forward (model.py:63-67) on caller-provided states. */
 int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, float *d_out198, void *stream);

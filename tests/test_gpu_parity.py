@@ -323,6 +323,34 @@ def test_epsilon_greedy_explores(bg, weights):
     assert 0.15 < frac < 0.55          # about half explore, some explorations hit the greedy index
 
 
+def test_epsilon_exploration_matches_stream_definition(bg, O, weights):
+    """model.py:205-206 with the Philox TURN stream: a lane explores iff (x3 >> 8) * 2^-24 < eps and then plays
+    reference-order candidate k = (x2 * C) >> 32 -- checked lane by lane against the oracle's enumeration."""
+    n, eps = 2048, 0.35
+    env = bg.VecGame(n, seed=321)
+    env.load_weights(weights)
+    for _ in range(12):
+        env.step_greedy()
+    pre, pt = _np(env.states()), _np(env.turns())
+    ply, epi = [_np(x) for x in env.progress()]
+    env.step_greedy(epsilon=eps, auto_reset=False)
+    post, ch = _np(env.states()), _np(env.last_choice()["chosen"])
+    n_explore = 0
+    for lane in range(n):
+        gid = lane + int(epi[lane]) * n
+        d1, d2, cu, eu = O.turn_randoms(321, gid, int(ply[lane]))
+        if not (np.float32(eu >> 8) * np.float32(1.0 / 16777216.0) < np.float32(eps)):
+            continue
+        _, _, cand = O.evaluate_turn_sequences(O.State.from28(pre[lane], pt[lane]), int(pt[lane]), d1, d2)
+        if len(cand) == 0:
+            assert (post[lane] == pre[lane]).all()
+            continue
+        k = (cu * len(cand)) >> 32
+        assert ch[lane] == k and (post[lane] == cand[k]).all(), lane
+        n_explore += 1
+    assert 0.25 * n < n_explore < 0.45 * n
+
+
 # ---- scalar Game surface (the reference's own tests, run through the drop-in module) ---------------------
 
 def test_scalar_game_known_answers(bg):
@@ -376,3 +404,45 @@ def test_scalar_make_move_like_reference_tests(bg, weights):
     assert b[16] == 2 and b[18] == 4 and b[19] == 2
     x = m.encode_state_np(g)
     assert x.shape == (198,) and x[192] == 1.0 and x[193] == 0.0
+
+
+# ---- trajectory log + TD(lambda) learner ---------------------------------------------
+
+def test_trajectory_log_and_learner_round(bg, O, weights):
+    """play_round logs the PRE-move state of every turn (train.py:105-106) as 32-byte rows; the rows decode to
+    exactly the states the env held, their device encoding equals the oracle's encoder bit for bit, and the
+    lock-step TD(λ) replay on the GPU equals the same replay on the CPU."""
+    from backgammon_env.learner import TDLambdaLearner, play_round
+    n = 256
+    env = bg.VecGame(n, seed=77)
+    env.load_weights(weights)
+    # 1. log vs the states observed from outside
+    traj = env.record_trajectory(64)
+    env.reset()
+    seen_s, seen_t = [], []
+    for t in range(20):
+        seen_s.append(_np(env.states())); seen_t.append(_np(env.turns()))
+        env.step_greedy(auto_reset=False)
+    X = _np(env.encode_rows(traj[:20]))
+    for t in range(20):
+        for tb in (0, 1):
+            m = seen_t[t] == tb
+            assert np.array_equal(X[t][m], O.encode(seen_s[t][m], tb)), t
+    env.record_trajectory(None)
+    # 2. a full round, then the replay on GPU vs CPU
+    rows, lengths, p1_won = play_round(env, max_plies=400)
+    ln = _np(lengths)
+    assert (ln > 20).all() and ln.max() <= rows.shape[0]
+    st = env.stats()
+    Xr = env.encode_rows(rows)
+    Lg = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.9)
+    sq_g, cnt_g = Lg.replay(Xr, lengths, p1_won)
+    Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.9)
+    sq_c, cnt_c = Lc.replay(Xr.cpu(), lengths.cpu(), p1_won.cpu())
+    assert cnt_g == cnt_c == int(ln.sum())
+    d = np.abs(Lg.theta.cpu().numpy() - Lc.theta.numpy()).max()
+    moved = np.abs(Lc.theta.numpy() - weights).max()
+    assert d < 1e-4 * max(1.0, moved) and moved > 1e-3
+    env.load_weights(Lg.theta.cpu().numpy())              # the next round plays with the updated net
+    env.reset(); env.step_greedy()
+    assert env.stats()["error_flags"] == 0 and st["games_finished"] >= n
