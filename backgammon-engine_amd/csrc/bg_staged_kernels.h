@@ -83,104 +83,65 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
     if (g < e.n) sv.best[g] = 0ull;
 }
 
-// ---- doubles ply 2 (LEVEL 1: D1 -> D2/F) and ply 3 (LEVEL 2: D2 -> F) ----------------------------
-template <int LEVEL>
-__global__ __launch_bounds__(256) void expand_kernel(EnvView e, StagedView sv)
+// ---- one ply per launch, with exact de-duplication inside the workgroup ------------------------------
+// stage_kernel<MODE>: a block takes STAGE_THREADS nodes; every node contributes its successor positions
+// (<= 15: one per legal origin; a node with no legal move, or at full depth, contributes itself).  The
+// successors are staged in LDS in rounds of at most STAGE_CAP rows and de-duplicated through an LDS hash
+// (slot = the copy with the SMALLEST reference key among identical (game, 256-bit position)).  Only the
+// representatives leave the CU:
+//   MODE_PLY2  (in: D1)  children -> D2, stuck nodes -> F      doubles after 2 moves
+//   MODE_PLY3  (in: D2)  everything -> F                       doubles after 3 moves (leaf parents)
+//   MODE_LEAF  (in: F)   everything -> u_rows / u_info         afterstates handed to the value net
+// Dropping a duplicate NODE drops its whole subtree: identical positions have identical subtrees, and the
+// surviving copy has the smaller key prefix, so every afterstate keeps its smallest-key representative.
+enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
+constexpr int STAGE_THREADS = 512;
+constexpr int STAGE_CAP = 2048;            // staged rows per round (40 B each, SoA)
+constexpr int STAGE_T = 4096;              // hash slots
+constexpr uint32_t STAGE_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
+constexpr uint32_t INFO_SELF = 0x40000000u;   // staged entry is the node itself (stuck), not a child
+
+template <int MODE>
+__global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedView sv)
 {
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_row[10][STAGE_CAP];  // p0..p7, game, key | flags
+    __shared__ uint32_t s_tab[STAGE_T];
+    __shared__ uint16_t s_pos[STAGE_CAP];
+    __shared__ uint32_t s_wave[STAGE_THREADS / 64];
     __shared__ unsigned long long s_slot;
-    const Node *in = LEVEL == 1 ? sv.d1 : sv.d2;
-    const unsigned long long cap_in = (unsigned long long)(LEVEL == 1 ? sv.cap_d1 : sv.cap_d2);
-    unsigned long long n_in = sv.tops[LEVEL == 1 ? T_D1 : T_D2];
+    constexpr int NW = STAGE_THREADS / 64;
+    const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
+    const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
+    unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
     if (n_in > cap_in) n_in = cap_in;
-    for (unsigned long long blk = blockIdx.x; blk * 256 < n_in; blk += gridDim.x) {
-        const unsigned long long i = blk * 256 + threadIdx.x;
-        const bool valid = i < n_in;
-        Node nd{0u, 0u};
-        NodeState s;
-        uint32_t m = 0;
-        if (valid) {
-            nd = in[i];
-            node_state(e, nd, s);
-            m = legal_origins(s.own, s.opp, s.pl, s.dA);
-        }
-        // stuck here -> the node itself is a leaf (goes to F unchanged); otherwise its children go on
-        const uint32_t nkids = (uint32_t)__popc(m);
-        const uint32_t nF = !valid ? 0u : (m == 0 ? 1u : (LEVEL == 2 ? nkids : 0u));
-        const uint32_t nD = (valid && LEVEL == 1) ? nkids : 0u;
-        uint32_t totF, totD = 0;
-        uint32_t offF = block_scan_256(nF, &totF, s_wave);
-        const unsigned long long baseF = block_alloc(&sv.tops[T_F], totF, &s_slot);
-        const bool okF = baseF + totF <= (unsigned long long)sv.cap_f;
-        uint32_t offD = 0;
-        unsigned long long baseD = 0;
-        bool okD = true;
-        if (LEVEL == 1) {
-            offD = block_scan_256(nD, &totD, s_wave);
-            baseD = block_alloc(&sv.tops[T_D2], totD, &s_slot);
-            okD = baseD + totD <= (unsigned long long)sv.cap_d2;
-        }
-        if (!okF || !okD) flag_overflow(e);
-        if (valid) {
-            if (m == 0) { if (okF) sv.f[baseF + offF] = nd; }
-            else {
-                while (m) {
-                    const int o = __ffs(m) - 1; m &= m - 1;
-                    const Node ch{nd.game, key_child(nd.key, o)};
-                    if (LEVEL == 1) { if (okD) sv.d2[baseD + offD++] = ch; }
-                    else { if (okF) sv.f[baseF + offF++] = ch; }
-                }
-            }
-        }
-    }
-}
-
-// ---- leaves: lane per leaf-parent, per-workgroup LDS staging + exact de-duplication ------------------
-// A block takes 256 leaf parents (<= 15 afterstates each).  Leaves are staged in LDS in rounds of at
-// most LEAF_CAP rows, de-duplicated through an LDS hash (slot = SMALLEST staging index among identical
-// (game, 256-bit row); inside a block staging order == reference order for rows of one game), and only
-// the representatives are written to HBM (u_rows / u_info).  Nothing else leaves the CU.
-constexpr int LEAF_THREADS = 512;          // leaf parents per block iteration
-constexpr int LEAF_CAP = 2048;             // staged rows per round (40 B each, SoA)
-constexpr int LEAF_T = 4096;               // hash slots
-constexpr uint32_t LEAF_EMPTY = 0xFFFFFFFFu;
-
-__global__ __launch_bounds__(LEAF_THREADS) void leaves_kernel(EnvView e, StagedView sv)
-{
-    __shared__ uint32_t s_row[10][LEAF_CAP];   // p0..p7, game, key|turn<<31
-    __shared__ uint32_t s_tab[LEAF_T];
-    __shared__ uint16_t s_pos[LEAF_CAP];
-    __shared__ uint32_t s_wave[LEAF_THREADS / 64];
-    __shared__ unsigned long long s_slot;
-    unsigned long long n_in = sv.tops[T_F];
-    if (n_in > (unsigned long long)sv.cap_f) n_in = (unsigned long long)sv.cap_f;
-    unsigned long long raw_total = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long staged_total = 0;
+    if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
-    for (unsigned long long blk = blockIdx.x; blk * LEAF_THREADS < n_in; blk += gridDim.x) {
-        const unsigned long long ni = blk * LEAF_THREADS + threadIdx.x;
+    for (unsigned long long blk = blockIdx.x; blk * STAGE_THREADS < n_in; blk += gridDim.x) {
+        const unsigned long long ni = blk * STAGE_THREADS + threadIdx.x;
         const bool valid = ni < n_in;
         Node nd{0u, 0u};
         NodeState s;
         uint32_t m0 = 0;
         int die = 1;
         if (valid) {
-            nd = sv.f[ni];
+            nd = in[ni];
             node_state(e, nd, s);
             die = (s.len & 1) ? s.dB : s.dA;
             if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
         }
         const uint32_t cnt = valid ? (m0 ? (uint32_t)__popc(m0) : 1u) : 0u;
         uint32_t total;
-        const uint32_t off = block_scan_256<LEAF_THREADS / 64>(cnt, &total, s_wave);
-        raw_total += total;
+        const uint32_t off = block_scan_256<NW>(cnt, &total, s_wave);
+        staged_total += total;
         const uint32_t info_turn = valid && s.pl ? 0x80000000u : 0u;
-        for (uint32_t r0 = 0; r0 < total; r0 += LEAF_CAP) {
-            const uint32_t nrow = total - r0 < (uint32_t)LEAF_CAP ? total - r0 : (uint32_t)LEAF_CAP;
-            for (int i = threadIdx.x; i < LEAF_T; i += LEAF_THREADS) s_tab[i] = LEAF_EMPTY;
-            // 1. stage this round's window [r0, r0 + nrow) of the block's leaves
+        for (uint32_t r0 = 0; r0 < total; r0 += STAGE_CAP) {
+            const uint32_t nrow = total - r0 < (uint32_t)STAGE_CAP ? total - r0 : (uint32_t)STAGE_CAP;
+            for (int i = threadIdx.x; i < STAGE_T; i += STAGE_THREADS) s_tab[i] = STAGE_EMPTY;
+            // 1. stage this round's window [r0, r0 + nrow) of the block's successors
             if (cnt && off < r0 + nrow && off + cnt > r0) {
                 uint32_t m = m0, j = off;
                 do {
@@ -188,7 +149,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void leaves_kernel(EnvView e, StagedV
                     if (m) { o = __ffs(m) - 1; m &= m - 1; }
                     if (j >= r0 && j < r0 + nrow) {
                         Side a = s.own, b = s.opp;
-                        uint32_t key = nd.key;
+                        uint32_t key = nd.key | INFO_SELF;
                         if (o >= 0) { apply_move(a, b, s.pl, o, die); key = key_child(nd.key, o); }
                         const Side &s1 = s.pl ? b : a, &s2 = s.pl ? a : b;
                         const uint32_t q = j - r0;
@@ -202,45 +163,75 @@ __global__ __launch_bounds__(LEAF_THREADS) void leaves_kernel(EnvView e, StagedV
             }
             __syncthreads();
             // 2. hash insert
-            for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) {
+            for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
                 uint32_t p[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) p[k] = s_row[k][i];
                 const uint32_t game = s_row[8][i];
-                uint32_t h = hash_row(p, game) & (LEAF_T - 1);
+                uint32_t h = hash_row(p, game) & (STAGE_T - 1);
                 for (;;) {
-                    const uint32_t cur = atomicCAS(&s_tab[h], LEAF_EMPTY, i);
-                    if (cur == LEAF_EMPTY) break;
+                    const uint32_t cur = atomicCAS(&s_tab[h], STAGE_EMPTY, i);
+                    if (cur == STAGE_EMPTY) break;
                     bool same = s_row[8][cur] == game;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) same = same && (s_row[k][cur] == p[k]);
-                    if (same) { atomicMin(&s_tab[h], i); break; }
-                    h = (h + 1) & (LEAF_T - 1);
+                    if (same) {
+                        // the slot keeps the copy with the SMALLEST reference key (list order across blocks of the
+                        // previous ply is arbitrary, so staging order alone does not give key order)
+                        const uint32_t mykey = s_row[9][i] & KEY_MASK;
+                        uint32_t c = cur;
+                        while (mykey < (s_row[9][c] & KEY_MASK)) {
+                            const uint32_t old = atomicCAS(&s_tab[h], c, i);
+                            if (old == c) break;
+                            c = old;
+                        }
+                        break;
+                    }
+                    h = (h + 1) & (STAGE_T - 1);
                 }
                 s_pos[i] = (uint16_t)h;
             }
             __syncthreads();
-            // 3. representatives -> unique arena (order is irrelevant: the key carries it)
-            uint32_t mine = 0;
-            for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) mine += (s_tab[s_pos[i]] == i) ? 1u : 0u;
-            uint32_t tot2;
-            uint32_t off2 = block_scan_256<LEAF_THREADS / 64>(mine, &tot2, s_wave);
-            const unsigned long long base2 = block_alloc(&sv.tops[T_U], tot2, &s_slot);
-            const bool ok = base2 + tot2 <= (unsigned long long)sv.cap_rows;
+            // 3. representatives leave the CU (their order is irrelevant: the key carries it)
+            uint32_t mineA = 0, mineB = 0;     // A: next node list / unique rows, B: stuck nodes of MODE_PLY2 -> F
+            for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
+                if (s_tab[s_pos[i]] != i) continue;
+                if (MODE == MODE_PLY2 && (s_row[9][i] & INFO_SELF)) ++mineB; else ++mineA;
+            }
+            uint32_t totA, totB = 0;
+            uint32_t offA = block_scan_256<NW>(mineA, &totA, s_wave);
+            unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
+            const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
+            const unsigned long long baseA = block_alloc(topA, totA, &s_slot);
+            uint32_t offB = 0;
+            unsigned long long baseB = 0;
+            if (MODE == MODE_PLY2) {
+                offB = block_scan_256<NW>(mineB, &totB, s_wave);
+                baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
+            }
+            const bool ok = baseA + totA <= capA && baseB + totB <= (unsigned long long)sv.cap_f;
             if (!ok) flag_overflow(e);
             if (ok) {
-                for (uint32_t i = threadIdx.x; i < nrow; i += LEAF_THREADS) {
+                for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
                     if (s_tab[s_pos[i]] != i) continue;
-                    const unsigned long long d = base2 + off2++;
-                    sv.u_rows[2 * d] = make_uint4(s_row[0][i], s_row[1][i], s_row[2][i], s_row[3][i]);
-                    sv.u_rows[2 * d + 1] = make_uint4(s_row[4][i], s_row[5][i], s_row[6][i], s_row[7][i]);
-                    sv.u_info[d] = make_uint2(s_row[8][i], s_row[9][i]);
+                    const uint32_t info = s_row[9][i];
+                    if (MODE == MODE_LEAF) {
+                        const unsigned long long d = baseA + offA++;
+                        sv.u_rows[2 * d] = make_uint4(s_row[0][i], s_row[1][i], s_row[2][i], s_row[3][i]);
+                        sv.u_rows[2 * d + 1] = make_uint4(s_row[4][i], s_row[5][i], s_row[6][i], s_row[7][i]);
+                        sv.u_info[d] = make_uint2(s_row[8][i], info & ~INFO_SELF);
+                    } else {
+                        const Node out{s_row[8][i], info & 0x3FFFFFFFu};
+                        if (MODE == MODE_PLY2 && (info & INFO_SELF)) sv.f[baseB + offB++] = out;
+                        else if (MODE == MODE_PLY2) sv.d2[baseA + offA++] = out;
+                        else sv.f[baseA + offA++] = out;
+                    }
                 }
             }
             __syncthreads();                   // s_row / s_tab / s_pos are rewritten by the next round
         }
     }
-    if (threadIdx.x == 0 && raw_total) atomicAdd(&e.counters[C_CAND_RAW], raw_total);
+    if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
 }
 
 // finds the reference-order index of a given sequence and the list length (BGAMD_WANT_INDEX)

@@ -83,7 +83,8 @@ def cpu_baseline(weights, budget_s=12.0):
 
 
 def distinct_ratio(env, sample_lanes=4096):
-    """U/C on the current boards: distinct afterstates / raw candidates over a lane sample."""
+    """Distinct afterstates U and raw reference-order candidates C per env step, measured on a lane sample of the
+    current boards through the ordered enumeration (the throughput path never materialises the raw list)."""
     offs, cnts, st, _, _ = env.enumerate()
     offs, cnts, st = offs.cpu().numpy(), cnts.cpu().numpy(), st.cpu().numpy()
     u = c = 0
@@ -92,7 +93,8 @@ def distinct_ratio(env, sample_lanes=4096):
         if k:
             u += len(np.unique(st[offs[lane]:offs[lane] + k], axis=0))
             c += k
-    return (u / c) if c else 1.0
+    lanes = len(range(0, env.n, max(1, env.n // sample_lanes)))
+    return u / lanes, c / lanes              # distinct afterstates and raw candidates per env step
 
 
 def main():
@@ -155,7 +157,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    ratio = distinct_ratio(env)
+    u_step, c_step = distinct_ratio(env)
     out = {
         "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -164,15 +166,17 @@ def main():
         "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
                                "(tdgammonNEW100k weights), auto-reset, Philox dice",
                    "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
-                   "candidates_per_step": round(tot["candidates_raw"] / max(tot["steps"], 1), 2),
-                   "distinct_over_raw": round(ratio, 4), "games_finished": tot["games_finished"]},
+                   "raw_candidates_per_step": round(c_step, 2), "distinct_afterstates_per_step": round(u_step, 2),
+                   "staged_leaves_per_step": round(tot["candidates_raw"] / max(tot["steps"], 1), 2),
+                   "rows_evaluated_per_step": round(tot["rows_evaluated"] / max(tot["steps"], 1), 2),
+                   "games_finished": tot["games_finished"]},
     }
     if kt:
         nl = max(kt["eval"]["launches"], 1)
         per = {k: (v["ms"] / v["launches"] if v["launches"] else 0.0) for k, v in kt.items()}
         rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
         fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
-        u_l = raw_l * ratio                                    # distinct afterstates per launch (sampled ratio)
+        u_l = steps_l * u_step                                 # distinct afterstates per launch (sampled U per step)
         eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
         # algorithmic bytes: leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
         # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
