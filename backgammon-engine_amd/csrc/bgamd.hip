@@ -574,6 +574,8 @@ struct bgamd_env {
     uint32_t *turn_before = nullptr;       // [n] mover of the last step
     float *d_w = nullptr;                  // raw weights 25601
     float4 *d_wl = nullptr;                // fp32 MFMA layout [99][64]
+    uint4 *d_wl16 = nullptr;               // bf16 MFMA layout [13][4][64] x 8 bf16
+    uint2 *d_lut = nullptr;                // count -> 4 bf16 features
     bool has_weights = false;
     int n_cu = 256;
     // kernel timing
@@ -684,6 +686,9 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     HIPCHK(hipMalloc(&v.counters, C_COUNT * 8));
     HIPCHK(hipMalloc(&env->d_w, N_PARAMS * 4));
     HIPCHK(hipMalloc(&env->d_wl, EVAL_LDS_BYTES));
+    HIPCHK(hipMalloc(&env->d_wl16, EVAL16_W_BYTES));
+    HIPCHK(hipMalloc(&env->d_lut, EVAL16_LUT_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16_LDS_TOTAL));
     {   // staged greedy step (bg_staged.h): node lists, per-workgroup staging, unique arena
         StagedView &sv = env->sv;
         const long long ng = n_games;
@@ -715,7 +720,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl,
+                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl, env->d_wl16, env->d_lut,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -862,6 +867,12 @@ int bgamd_env_load_weights(bgamd_env *env, const float *h_weights)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(env->d_w, h_weights, N_PARAMS * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(env->d_wl, wl.data(), EVAL_LDS_BYTES, hipMemcpyHostToDevice));
+    std::vector<uint16_t> wl16((size_t)K16_STEPS * 4 * 64 * 8);
+    relayout_w1_bf16(h_weights, wl16.data());
+    uint32_t lut[32];
+    make_count_lut(lut);
+    HIPCHK(hipMemcpy(env->d_wl16, wl16.data(), EVAL16_W_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_lut, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
     env->has_weights = true;
     return BGAMD_OK;
 }
@@ -869,9 +880,14 @@ int bgamd_env_load_weights(bgamd_env *env, const float *h_weights)
 static int launch_eval(bgamd_env *env, int precision, const unsigned long long *n_rows_ptr, long long n_rows_imm,
                        const uint4 *rows, float *values, const uint2 *info, unsigned long long *best, hipStream_t s)
 {
-    if (precision != BGAMD_F32) return BGAMD_E_INVALID;     // bf16 path: later round
+    if (precision != BGAMD_F32 && precision != BGAMD_BF16) return BGAMD_E_INVALID;
     const float *b1 = env->d_w + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
-    {
+    if (precision == BGAMD_BF16) {
+        KTimer t(env, s, 1);
+        hipLaunchKernelGGL(eval_rows_bf16_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16_LDS_TOTAL, s, rows, n_rows_ptr,
+                           n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
+                           (const uint4 *)env->d_wl16, (const uint2 *)env->d_lut, b1, w2, b2, values, info, best);
+    } else {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,

@@ -28,7 +28,7 @@ import torch.distributed as dist  # noqa: E402
 GAMES_PER_GPU = 65536
 SEED = 20240603
 FLOP_PER_ROW = 2 * 198 * 128 + 2 * 128          # 50 944, SURVEY.md §8d
-PEAK = {"f32": 157.3, "hbm": 8000.0}            # TFLOP/s dense fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
+PEAK = {"f32": 157.3, "bf16": 2500.0, "hbm": 8000.0}   # TFLOP/s dense MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(weights, budget_s=12.0):
@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
     ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
+    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+                    help="value-net arithmetic; f32 is the parity mode (1e-5 vs the reference) and the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -127,8 +129,9 @@ def main():
     env = bg.VecGame(a.games, device=local_rank, seed=SEED, lane_offset=off, lane_stride=stride,
                      arena_rows=a.games * 512)
     env.load_weights(w)
+    prec = bg.BF16 if a.precision == "bf16" else bg.F32
     for _ in range(a.burnin + a.warmup):
-        env.step_greedy()
+        env.step_greedy(precision=prec)
     torch.cuda.synchronize()
     env.stats()                                   # raises on arena overflow
     env.reset_stats()
@@ -141,7 +144,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        env.step_greedy()
+        env.step_greedy(precision=prec)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,7 +165,7 @@ def main():
         "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
                                "(tdgammonNEW100k weights), auto-reset, Philox dice",
                    "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
@@ -183,8 +186,8 @@ def main():
         leaves_gbs = (fn_l * 52 + u_l * 40) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
         expand_gbs = (steps_l * 52 + (fn_l + 2 * dn_l) * 8 + dn_l * 44) / (per["expand"] * 1e-3) / 1e9 if per["expand"] else 0.0
         roofs = {
-            "eval": {"kernel": "eval_rows_f32_kernel", "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK["f32"],
-                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK["f32"], 4), "traffic": None, "avg_ms": round(per["eval"], 4),
+            "eval": {"kernel": "eval_rows_%s_kernel" % a.precision, "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK[a.precision],
+                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK[a.precision], 4), "traffic": None, "avg_ms": round(per["eval"], 4),
                      "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)},
             "leaves": {"kernel": "leaves_kernel", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
@@ -196,7 +199,7 @@ def main():
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            for name, key in (("eval", "eval_rows_f32_kernel"), ("leaves", "leaves_kernel")):
+            for name, key in (("eval", "eval_rows_%s_kernel" % a.precision), ("leaves", "stage_kernel<3>")):
                 if key in pmc:
                     roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
                     roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per launch)"
