@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void apply_kernel(EnvView e, StagedView sv, int
             SelectVisitor sel(k);
             walk_sequences(own, opp, c.turn, c.d1, c.d2, sel);
             own = sel.own; opp = sel.opp;
-            cseq = sel.seq; chosen = (int32_t)k; ccount = cv.n; cval = 0.0f;
+            cseq = sel.seq | (c.turn ? (1u << 29) : 0u); chosen = (int32_t)k; ccount = cv.n; cval = 0.0f;
         } else {
             const int len = key_len(key), pass = key_pass(key);
             const int dA = pass ? c.d2 : c.d1, dB = pass ? c.d1 : c.d2;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64) void apply_kernel(EnvView e, StagedView sv, int
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < len) apply_move(own, opp, c.turn, key_origin(key, k), (k & 1) ? dB : dA);
-            cseq = seq_pack(origins, len, dA, dB);
+            cseq = seq_pack(origins, len, dA, dB) | (c.turn ? (1u << 29) : 0u);   // bit 29: mover moves down
         }
         join_sides(own, opp, c.turn, c.p);
     }

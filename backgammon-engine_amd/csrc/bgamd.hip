@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void step_random_kernel(EnvView e, int flags, c
         SelectVisitor sv(k);
         walk_sequences(own, opp, c.turn, c.d1, c.d2, sv);
         join_sides(sv.own, sv.opp, c.turn, c.p);
-        chosen = (int32_t)k; cseq = sv.seq;
+        chosen = (int32_t)k; cseq = sv.seq | (c.turn ? (1u << 29) : 0u);   // bit 29: mover moves down (unpack_seq)
     }
     if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.cand_cnt[g] = C; e.chosen_val[g] = 0.0f; }
     const unsigned long long tot = wave_sum_u32(C);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void select_apply_kernel(EnvView e, int flags, 
         c.p[4] = u1.x; c.p[5] = u1.y; c.p[6] = u1.z; c.p[7] = u1.w;
         chosen = (int32_t)idx;
         cval = e.values[r];
-        if (have_seq) cseq = e.seqs[r];
+        if (have_seq) cseq = e.seqs[r] | (c.turn ? (1u << 29) : 0u);
     }
     if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.chosen_val[g] = cval; }
     finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
@@ -544,13 +544,6 @@ __global__ void legal_moves_kernel(EnvView e, const int32_t *__restrict__ player
 
 #include "bg_staged_kernels.h"
 
-// marks the mover's direction in the packed sequences of the last step (bit 29) -- see unpack_seq
-__global__ void tag_chosen_seq_kernel(EnvView e, const uint32_t *__restrict__ turn_before)
-{
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < e.n && (turn_before[g] & 1u)) e.chosen_seq[g] |= 1u << 29;
-}
-
 }  // namespace
 
 // ================================================================================================
@@ -571,7 +564,6 @@ struct bgamd_env {
     int device = 0;
     EnvView v{};
     StagedView sv{};
-    uint32_t *turn_before = nullptr;       // [n] mover of the last step
     float *d_w = nullptr;                  // raw weights 25601
     float4 *d_wl = nullptr;                // fp32 MFMA layout [99][64]
     uint4 *d_wl16 = nullptr;               // bf16 MFMA layout [13][4][64] x 8 bf16
@@ -679,7 +671,6 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     HIPCHK(hipMalloc(&v.chosen, n * 4));
     HIPCHK(hipMalloc(&v.chosen_seq, n * 4));
     HIPCHK(hipMalloc(&v.chosen_val, n * 4));
-    HIPCHK(hipMalloc(&env->turn_before, n * 4));
     HIPCHK(hipMalloc(&v.rows, (size_t)cap * 32));
     HIPCHK(hipMalloc(&v.seqs, (size_t)cap * 4));
     HIPCHK(hipMalloc(&v.values, (size_t)cap * 4));
@@ -720,7 +711,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, env->turn_before, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl, env->d_wl16, env->d_lut,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl, env->d_wl16, env->d_lut,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -737,7 +728,6 @@ int bgamd_env_reset(bgamd_env *env, void *stream)
     HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v);
     HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, s));
-    HIPCHK(hipMemsetAsync(env->turn_before, 0, (size_t)env->v.n * 4, s));
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -837,23 +827,14 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
     return BGAMD_OK;
 }
 
-static int snapshot_turn(bgamd_env *env, hipStream_t s)
-{
-    HIPCHK(hipMemcpyAsync(env->turn_before, env->v.meta, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
-    return BGAMD_OK;
-}
-
 int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream)
 {
     if (!env) return BGAMD_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    int rc = snapshot_turn(env, s);
-    if (rc) return rc;
     {
         KTimer t(env, s, 3);
         hipLaunchKernelGGL(step_random_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, d_choice_u32);
     }
-    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, env->turn_before);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -902,8 +883,7 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     if (!env) return BGAMD_E_INVALID;
     if (!env->has_weights) return BGAMD_E_NOWEIGHTS;
     hipStream_t s = (hipStream_t)stream;
-    int rc = snapshot_turn(env, s);
-    if (rc) return rc;
+    int rc;
     StagedView &sv = env->sv;
     const long long n = env->v.n;
     HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
@@ -928,7 +908,6 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         KTimer t(env, s, 2);
         hipLaunchKernelGGL(apply_kernel, grid1(n, 64), dim3(64), 0, s, env->v, sv, flags, epsilon);
     }
-    hipLaunchKernelGGL(tag_chosen_seq_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->turn_before);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
