@@ -44,6 +44,7 @@ SYMBOLS = [
     ("bgamd_env_reset_stats", C.c_int, [_P, _P]),
     ("bgamd_env_try_move", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("bgamd_env_legal_moves", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("bgamd_env_unique_rows_info", C.c_int64, [_P, _P, C.c_int64, _P]),
     ("bgamd_env_set_trajectory", C.c_int, [_P, _P, C.c_int64]),
     ("bgamd_env_get_progress", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_encode_rows", C.c_int, [_P, C.c_int64, _P, _P]),

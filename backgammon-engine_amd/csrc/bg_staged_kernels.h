@@ -192,9 +192,13 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedV
                 s_pos[i] = (uint16_t)h;
             }
             __syncthreads();
-            // 3. representatives leave the CU (their order is irrelevant: the key carries it)
+            // 3. representatives leave the CU.  Correctness does not depend on their order (the key carries it),
+            //    but locality does: each thread compacts a CONTIGUOUS slice so that a game's nodes stay adjacent
+            //    in the output list and meet again in one block of the next ply
+            const uint32_t slice = (nrow + STAGE_THREADS - 1) / STAGE_THREADS;
+            const uint32_t lo = threadIdx.x * slice, hi = lo + slice < nrow ? lo + slice : nrow;
             uint32_t mineA = 0, mineB = 0;     // A: next node list / unique rows, B: stuck nodes of MODE_PLY2 -> F
-            for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
+            for (uint32_t i = lo; i < hi; ++i) {
                 if (s_tab[s_pos[i]] != i) continue;
                 if (MODE == MODE_PLY2 && (s_row[9][i] & INFO_SELF)) ++mineB; else ++mineA;
             }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedV
             const bool ok = baseA + totA <= capA && baseB + totB <= (unsigned long long)sv.cap_f;
             if (!ok) flag_overflow(e);
             if (ok) {
-                for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
+                for (uint32_t i = lo; i < hi; ++i) {
                     if (s_tab[s_pos[i]] != i) continue;
                     const uint32_t info = s_row[9][i];
                     if (MODE == MODE_LEAF) {

@@ -962,6 +962,19 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
     return BGAMD_OK;
 }
 
+int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info, int64_t cap, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpyAsync(&n, &env->sv.tops[T_U], 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if ((long long)n > env->sv.cap_rows) n = (unsigned long long)env->sv.cap_rows;
+    const long long m = (long long)n < cap ? (long long)n : cap;
+    if (d_info && m > 0) HIPCHK(hipMemcpyAsync(d_info, env->sv.u_info, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+    return (int64_t)n;
+}
+
 int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies)
 {
     if (!env || (d_rows && max_plies <= 0)) return BGAMD_E_INVALID;

@@ -129,6 +129,10 @@ int bgamd_env_try_move(bgamd_env *env, const int32_t *d_player, const int32_t *d
 int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t *d_die,
                           int32_t *d_n, int8_t *d_pairs /*[n,26,2]*/, void *stream);
 
+/* diagnostics: (game, key | turn<<31) of every row the value net evaluated in the last greedy step (after the
+ * in-workgroup de-duplication); returns the row count (synchronises). */
+int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info /* uint32[cap][2] */, int64_t cap, void *stream);
+
 /* ---- trajectory log for the learner (the list of encodings play_game returns, train.py:105-106,
  * kept as 32-byte rows: 8 bit planes, turn of the side to move in plane 0 bit 31).  When set, every
  * greedy step stores the PRE-move row of each live lane at d_rows[(ply*n + lane)*32 B]; plies >=
