@@ -82,18 +82,22 @@ def cpu_baseline(weights, budget_s=12.0):
     return out
 
 
-def distinct_ratio(env, sample_lanes=4096):
-    """Distinct afterstates U and raw reference-order candidates C per env step, measured on a lane sample of the
-    current boards through the ordered enumeration (the throughput path never materialises the raw list)."""
-    offs, cnts, st, _, _ = env.enumerate()
-    offs, cnts, st = offs.cpu().numpy(), cnts.cpu().numpy(), st.cpu().numpy()
-    u = c = 0
-    for lane in range(0, env.n, max(1, env.n // sample_lanes)):
-        k = int(cnts[lane])
-        if k:
-            u += len(np.unique(st[offs[lane]:offs[lane] + k], axis=0))
-            c += k
-    lanes = len(range(0, env.n, max(1, env.n // sample_lanes)))
+def distinct_ratio(env, prec, sample_lanes=2048, samples=4):
+    """Distinct afterstates U and raw reference-order candidates C per env step, measured after the timed region
+    on lane samples of `samples` consecutive steps through the ordered enumeration (the throughput path never
+    materialises the raw list)."""
+    u = c = lanes = 0
+    for k in range(samples):
+        env.roll()
+        offs, cnts, st, _, _ = env.enumerate()
+        offs, cnts, st = offs.cpu().numpy(), cnts.cpu().numpy(), st.cpu().numpy()
+        for lane in range(k, env.n, max(1, env.n // sample_lanes)):
+            n = int(cnts[lane])
+            lanes += 1
+            if n:
+                u += len(np.unique(st[offs[lane]:offs[lane] + n], axis=0))
+                c += n
+        env.step_greedy(precision=prec)
     return u / lanes, c / lanes              # distinct afterstates and raw candidates per env step
 
 
@@ -160,7 +164,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    u_step, c_step = distinct_ratio(env)
+    u_step, c_step = distinct_ratio(env, prec)
     out = {
         "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
