@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import AUTO_RESET, BF16, F32, NO_FLIP, ROLL, WANT_INDEX, BgamdError  # noqa: F401
+from ._capi import (AUTO_RESET, BF16, F32, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
+                    BgamdError)
 
 __all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed"]
 
@@ -175,8 +176,8 @@ class VecGame:
         return offs, cnts, st, sq, ln
 
     # -- the env step
-    def load_weights(self, weights):
-        """weights: flat float32[25601] = W1[128,198] | b1[128] | W2[128] | b2[1], or a state_dict with
+    def load_weights(self, weights, slot: int = 0):
+        """slot 0 | 1 (head-to-head play keeps one weight set per side).  weights: flat float32[25601] = W1[128,198] | b1[128] | W2[128] | b2[1], or a state_dict with
         fc1.weight / fc1.bias / fc2.weight / fc2.bias (the reference checkpoints, train.py:513-515)."""
         if isinstance(weights, dict):
             weights = np.concatenate([np.asarray(weights[k].detach().cpu().float()).ravel()
@@ -184,25 +185,30 @@ class VecGame:
         w = np.ascontiguousarray(np.asarray(weights, dtype=np.float32).ravel())
         if w.size != 25601:
             raise ValueError("expected 25601 weights (198->128->1)")
-        _capi.check(self._lib.bgamd_env_load_weights(self._h, w.ctypes.data_as(C.c_void_p)), "load_weights")
+        _capi.check(self._lib.bgamd_env_load_weights_slot(self._h, int(slot), w.ctypes.data_as(C.c_void_p)), "load_weights")
         self._has_weights = True
 
     @staticmethod
-    def _flags(roll, auto_reset, no_flip=False):
-        return (ROLL if roll else 0) | (AUTO_RESET if auto_reset else 0) | (NO_FLIP if no_flip else 0)
+    def _flags(roll, auto_reset, no_flip=False, only_player=None, slot=0):
+        f = (ROLL if roll else 0) | (AUTO_RESET if auto_reset else 0) | (NO_FLIP if no_flip else 0)
+        if only_player is not None:
+            f |= ONLY_P1 if int(only_player) == 0 else ONLY_P2
+        return f | (WEIGHTS_SLOT1 if slot else 0)
 
-    def step_random(self, roll=True, auto_reset=True, choice_u32=None, no_flip=False):
+    def step_random(self, roll=True, auto_reset=True, choice_u32=None, no_flip=False, only_player=None):
         c = None
         if choice_u32 is not None:
             c = torch.as_tensor(np.asarray(choice_u32, dtype=np.uint32).view(np.int32)).to(self.device).contiguous()
-        _capi.check(self._lib.bgamd_env_step_random(self._h, self._flags(roll, auto_reset, no_flip), _ptr(c), _stream()),
+        _capi.check(self._lib.bgamd_env_step_random(self._h, self._flags(roll, auto_reset, no_flip, only_player), _ptr(c), _stream()),
                     "step_random")
         if c is not None:
             torch.cuda.current_stream().synchronize()
 
-    def step_greedy(self, roll=True, auto_reset=True, epsilon=0.0, precision=F32, no_flip=False, want_index=False):
-        """want_index: also report the chosen reference-order index and the list length (slow path)."""
-        _capi.check(self._lib.bgamd_env_step_greedy(self._h, self._flags(roll, auto_reset, no_flip) |
+    def step_greedy(self, roll=True, auto_reset=True, epsilon=0.0, precision=F32, no_flip=False, want_index=False,
+                    only_player=None, slot=0):
+        """want_index: also report the chosen reference-order index and the list length (slow path).
+        only_player / slot: head-to-head play -- step only the lanes of that side with weight slot `slot`."""
+        _capi.check(self._lib.bgamd_env_step_greedy(self._h, self._flags(roll, auto_reset, no_flip, only_player, slot) |
                                                     (WANT_INDEX if want_index else 0), float(epsilon),
                                                     int(precision), _stream()), "step_greedy")
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbgamd.so")
 
 OK = 0
-ROLL, AUTO_RESET, NO_FLIP, WANT_INDEX = 1, 2, 4, 8
+ROLL, AUTO_RESET, NO_FLIP, WANT_INDEX, ONLY_P1, ONLY_P2, WEIGHTS_SLOT1 = 1, 2, 4, 8, 16, 32, 64
 F32, BF16 = 0, 1
 
 # every symbol include/bgamd.h declares: (name, restype, argtypes)
@@ -38,6 +38,7 @@ SYMBOLS = [
     ("bgamd_env_candidates_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     ("bgamd_env_step_random", C.c_int, [_P, C.c_int, _P, _P]),
     ("bgamd_env_load_weights", C.c_int, [_P, _P]),
+    ("bgamd_env_load_weights_slot", C.c_int, [_P, C.c_int, _P]),
     ("bgamd_env_step_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, _P]),
     ("bgamd_env_last_choice", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("bgamd_env_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),

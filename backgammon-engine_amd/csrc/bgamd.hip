@@ -124,6 +124,8 @@ __device__ __forceinline__ void lane_begin(const EnvView &e, long long g, int fl
     c.meta = e.meta[gg]; c.ply = e.ply[gg]; c.epi = e.episode[gg];
     if (c.meta & META_FINISHED) c.live = false;
     c.turn = c.meta & 1;
+    // head-to-head play (train.py:262-277): only the lanes whose side is to move take part in this call
+    if (((flags & BGAMD_ONLY_P1) && c.turn != 0) || ((flags & BGAMD_ONLY_P2) && c.turn != 1)) c.live = false;
     const unsigned long long gid = e.lane_offset + (unsigned long long)gg + (unsigned long long)c.epi * e.lane_stride;
     c.x = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), c.ply, STREAM_TURN, (uint32_t)e.seed, (uint32_t)(e.seed >> 32));
     if (flags & BGAMD_ROLL) { c.d1 = die_from_u32(c.x.x); c.d2 = die_from_u32(c.x.y); }
@@ -564,11 +566,11 @@ struct bgamd_env {
     int device = 0;
     EnvView v{};
     StagedView sv{};
-    float *d_w = nullptr;                  // raw weights 25601
-    float4 *d_wl = nullptr;                // fp32 MFMA layout [99][64]
-    uint4 *d_wl16 = nullptr;               // bf16 MFMA layout [13][4][64] x 8 bf16
+    float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
+    float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
+    uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint2 *d_lut = nullptr;                // count -> 4 bf16 features
-    bool has_weights = false;
+    bool has_weights[2] = {false, false};
     int n_cu = 256;
     // kernel timing
     bool timing = false;
@@ -675,9 +677,11 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     HIPCHK(hipMalloc(&v.seqs, (size_t)cap * 4));
     HIPCHK(hipMalloc(&v.values, (size_t)cap * 4));
     HIPCHK(hipMalloc(&v.counters, C_COUNT * 8));
-    HIPCHK(hipMalloc(&env->d_w, N_PARAMS * 4));
-    HIPCHK(hipMalloc(&env->d_wl, EVAL_LDS_BYTES));
-    HIPCHK(hipMalloc(&env->d_wl16, EVAL16_W_BYTES));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
+        HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
+        HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
+    }
     HIPCHK(hipMalloc(&env->d_lut, EVAL16_LUT_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16_LDS_TOTAL));
     {   // staged greedy step (bg_staged.h): node lists, per-workgroup staging, unique arena
@@ -711,7 +715,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w, env->d_wl, env->d_wl16, env->d_lut,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -839,40 +843,43 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
     return BGAMD_OK;
 }
 
-int bgamd_env_load_weights(bgamd_env *env, const float *h_weights)
+int bgamd_env_load_weights(bgamd_env *env, const float *h_weights) { return bgamd_env_load_weights_slot(env, 0, h_weights); }
+
+int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights)
 {
-    if (!env || !h_weights) return BGAMD_E_INVALID;
+    if (!env || !h_weights || slot < 0 || slot > 1) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(env->device));
     std::vector<float> wl((size_t)K_STEPS * 64 * 4);
     relayout_w1_f32(h_weights, wl.data());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(env->d_w, h_weights, N_PARAMS * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(env->d_wl, wl.data(), EVAL_LDS_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_w[slot], h_weights, N_PARAMS * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_wl[slot], wl.data(), EVAL_LDS_BYTES, hipMemcpyHostToDevice));
     std::vector<uint16_t> wl16((size_t)K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16(h_weights, wl16.data());
     uint32_t lut[32];
     make_count_lut(lut);
-    HIPCHK(hipMemcpy(env->d_wl16, wl16.data(), EVAL16_W_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_wl16[slot], wl16.data(), EVAL16_W_BYTES, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(env->d_lut, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
-    env->has_weights = true;
+    env->has_weights[slot] = true;
     return BGAMD_OK;
 }
 
-static int launch_eval(bgamd_env *env, int precision, const unsigned long long *n_rows_ptr, long long n_rows_imm,
+static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned long long *n_rows_ptr, long long n_rows_imm,
                        const uint4 *rows, float *values, const uint2 *info, unsigned long long *best, hipStream_t s)
 {
+    if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
     if (precision != BGAMD_F32 && precision != BGAMD_BF16) return BGAMD_E_INVALID;
-    const float *b1 = env->d_w + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
     if (precision == BGAMD_BF16) {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_bf16_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
-                           (const uint4 *)env->d_wl16, (const uint2 *)env->d_lut, b1, w2, b2, values, info, best);
+                           (const uint4 *)env->d_wl16[slot], (const uint2 *)env->d_lut, b1, w2, b2, values, info, best);
     } else {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
-                           (const float4 *)env->d_wl, b1, w2, b2, values, info, best);
+                           (const float4 *)env->d_wl[slot], b1, w2, b2, values, info, best);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -881,7 +888,8 @@ static int launch_eval(bgamd_env *env, int precision, const unsigned long long *
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream)
 {
     if (!env) return BGAMD_E_INVALID;
-    if (!env->has_weights) return BGAMD_E_NOWEIGHTS;
+    const int slot = (flags & BGAMD_WEIGHTS_SLOT1) ? 1 : 0;
+    if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     StagedView &sv = env->sv;
@@ -902,7 +910,7 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         KTimer t(env, s, 5);
         hipLaunchKernelGGL(stage_kernel<MODE_LEAF>, sgrid(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
     }
-    rc = launch_eval(env, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
+    rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
     if (rc) return rc;
     {
         KTimer t(env, s, 2);
@@ -1016,13 +1024,13 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
                    float *d_values, void *stream)
 {
     if (!env || !d_states28 || !d_values || n < 0 || n > env->v.cap) return BGAMD_E_INVALID;
-    if (!env->has_weights) return BGAMD_E_NOWEIGHTS;
+    if (!env->has_weights[0]) return BGAMD_E_NOWEIGHTS;
     if (n == 0) return BGAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     // the candidate arena doubles as scratch for caller-provided states
     hipLaunchKernelGGL(pack_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_turn, (long long)n, env->v.rows,
                        &env->v.counters[C_ERR]);
-    return launch_eval(env, precision, nullptr, (long long)n, env->v.rows, d_values, nullptr, nullptr, s);
+    return launch_eval(env, 0, precision, nullptr, (long long)n, env->v.rows, d_values, nullptr, nullptr, s);
 }
 
 int bgamd_env_time_kernels(bgamd_env *env, int enable)

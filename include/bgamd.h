@@ -46,9 +46,12 @@ enum {
                                  without it a finished game stays finished and is skipped      */
     BGAMD_NO_FLIP = 4,        /* do not flip the turn / advance ply (make_move semantics,
                                  model.py:180-222, for the scalar Game surface)                */
-    BGAMD_WANT_INDEX = 8      /* greedy step: also report the chosen move's index into the
+    BGAMD_WANT_INDEX = 8,     /* greedy step: also report the chosen move's index into the
                                  reference-order list and the list length (walks the whole list
                                  per lane: parity/debug use, not the throughput path)           */
+    BGAMD_ONLY_P1 = 16,       /* only lanes with PLAYER1 / PLAYER2 to move take part in this call  */
+    BGAMD_ONLY_P2 = 32,       /*   (head-to-head play of two policies, train.py:262-277)           */
+    BGAMD_WEIGHTS_SLOT1 = 64  /* greedy step evaluates with weight slot 1 instead of slot 0        */
 };
 
 enum { BGAMD_F32 = 0, BGAMD_BF16 = 1 };   /* value-net arithmetic */
@@ -112,7 +115,8 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
  * count, value of the chosen afterstate.  The greedy step reports index and count exactly only with
  * BGAMD_WANT_INDEX; without it index is 0 and count 1 when a move was made (-1 / 0 when none was). */
 int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
-int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);
+int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);   /* slot 0 */
+int bgamd_env_load_weights_slot(bgamd_env *env, int slot /* 0 | 1 */, const float *h_weights);
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);
 int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq /*[n,4,2]*/,
                           int32_t *d_seq_len, float *d_value, void *stream);

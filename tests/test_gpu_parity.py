@@ -494,3 +494,28 @@ def test_trajectory_log_and_learner_round(bg, O, weights):
     env.load_weights(Lg.theta.cpu().numpy())              # the next round plays with the updated net
     env.reset(); env.step_greedy()
     assert env.stats()["error_flags"] == 0 and st["games_finished"] >= n
+
+
+def test_head_to_head_two_weight_slots(bg, O, weights):
+    """train.py:262-277: PLAYER1's lanes are moved by one net, PLAYER2's by another (two weight slots,
+    BGAMD_ONLY_P1/P2).  Each side's move is value-optimal under ITS OWN weights, lanes of the other side do not
+    move, and the trained net beats a uniformly random mover."""
+    from backgammon_env.arena import head_to_head
+    n = 1024
+    rng = np.random.RandomState(3)
+    wb = (weights + rng.normal(0, 0.05, weights.shape)).astype(np.float32)
+    env = bg.VecGame(n, seed=41)
+    env.load_weights(weights, slot=0); env.load_weights(wb, slot=1)
+    env.reset()
+    for t in range(12):
+        for player, slot, w in ((0, 0, weights), (1, 1, wb)):
+            pre, pt = _np(env.states()), _np(env.turns())
+            env.step_greedy(auto_reset=False, only_player=player, slot=slot)
+            post, dice = _np(env.states()), _np(env.dice())
+            idle = pt != player
+            assert (post[idle] == pre[idle]).all() and (_np(env.turns())[idle] == pt[idle]).all()
+            if t % 3 == 0:
+                _check_greedy_step(O, w, pre, pt, dice, post, [l for l in range(t, n, 37) if not idle[l]])
+    r = head_to_head(bg.VecGame(512, seed=9), weights, None)
+    print("trained net vs random mover:", r)
+    assert r["games"] == 1024 and r["win_rate"] > 0.9
