@@ -52,7 +52,8 @@ class TDLambdaLearner:
         z = torch.as_tensor(p1_won, device=dev).to(dt)
         e = torch.zeros((G, 25601), dtype=dt, device=dev)       # traces are reset per game (train.py:539-540)
         eW1, eb1, eW2, eb2 = self._split(e)
-        sq, cnt = torch.zeros((), dtype=torch.float64, device=dev), 0
+        sq = torch.zeros((), dtype=torch.float64, device=dev)
+        cnt = torch.zeros((), dtype=torch.int64, device=dev)
         Tmax = int(lengths.max().item()) if G else 0
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         for t in range(min(T, Tmax)):
@@ -81,8 +82,8 @@ class TDLambdaLearner:
                 dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)   # the ONE collective per training step
             self.theta.add_(upd)
             sq += (delta.double() ** 2).sum()
-            cnt += int(active.sum().item())
-        return float(sq.item()), cnt
+            cnt += active.sum()                                     # no host sync inside the loop
+        return float(sq.item()), int(cnt.item())
 
     def state_dict(self):
         W1, b1, W2, b2 = self._split(self.theta.detach().cpu())

@@ -519,3 +519,58 @@ def test_head_to_head_two_weight_slots(bg, O, weights):
     r = head_to_head(bg.VecGame(512, seed=9), weights, None)
     print("trained net vs random mover:", r)
     assert r["games"] == 1024 and r["win_rate"] > 0.9
+
+
+def test_greedy_auto_reset_and_terminal_65536(bg, O, weights):
+    """BASELINE size under the greedy policy: games end, winners are the side that just bore off its 15th
+    checker, lanes restart from the start position with the opening-roll turn of the NEXT global game id,
+    checkers are conserved, and two identically seeded envs stay identical (determinism despite atomics)."""
+    n, steps = 65536, 120
+    a, b = bg.VecGame(n, seed=2024), bg.VecGame(n, seed=2024)
+    a.load_weights(weights); b.load_weights(weights)
+    start = np.array(START + [0, 0, 0, 0], dtype=np.int32)
+    n_reset = 0
+    for t in range(steps):
+        mover = _np(a.turns())
+        a.step_greedy(); b.step_greedy()
+        if t >= 40 and t % 8 == 0:
+            fl = (_np(a.flags()) >> 4) & 3
+            done = (fl & 1) == 1
+            if done.any():
+                st, tn = _np(a.states()), _np(a.turns())
+                _, epi = [_np(x) for x in a.progress()]
+                assert (st[done] == start).all()
+                assert (((fl >> 1) & 1)[done] == mover[done]).all()          # the mover won
+                for lane in np.where(done)[0][:64]:
+                    assert tn[lane] == O.lib().bgo_opening_turn(2024, int(lane) + int(epi[lane]) * n)
+                n_reset += int(done.sum())
+    sa = _np(a.states())
+    assert (sa == _np(b.states())).all() and (_np(a.turns()) == _np(b.turns())).all()
+    p1 = np.clip(sa[:, :24], 0, None).sum(1) + sa[:, 24] + sa[:, 26]
+    p2 = np.clip(-sa[:, :24], 0, None).sum(1) + sa[:, 25] + sa[:, 27]
+    assert (p1 == 15).all() and (p2 == 15).all()
+    s = a.stats()
+    assert s["steps"] == n * steps and s["games_finished"] > n // 2 and n_reset > 0 and s["error_flags"] == 0
+    sb = b.stats()
+    # results are deterministic; the WORK counters are not (how many duplicates meet in one block depends on the
+    # order in which blocks win the bump allocations)
+    assert all(s[k] == sb[k] for k in ("steps", "games_finished", "p1_wins", "error_flags"))
+
+
+def test_errors_are_loud(bg, weights):
+    """Arena overflow, out-of-range counts and missing weights are reported, never silently absorbed."""
+    env = bg.VecGame(64, arena_rows=65536)
+    with pytest.raises(bg.BgamdError):
+        env.step_greedy()                                     # no weights loaded
+    bad = np.tile(np.array(START + [0, 0, 0, 0], dtype=np.int32), (64, 1))
+    bad[3, 0] = 16
+    env.set_states(bad, np.zeros(64, dtype=np.int32))
+    with pytest.raises(bg.BgamdError):
+        env.stats()                                           # BGAMD_E_STATE
+    small = bg.VecGame(70000, arena_rows=65536)               # 70 000 lanes cannot enumerate into 65 536 rows
+    small.roll()
+    with pytest.raises(bg.BgamdError):
+        small.enumerate()                                     # BGAMD_E_ARENA
+    g = bg.Game(0)
+    with pytest.raises(ValueError):
+        g.setGameBoard([0] * 25)
