@@ -195,12 +195,13 @@ class VecGame:
             f |= ONLY_P1 if int(only_player) == 0 else ONLY_P2
         return f | (WEIGHTS_SLOT1 if slot else 0)
 
-    def step_random(self, roll=True, auto_reset=True, choice_u32=None, no_flip=False, only_player=None):
+    def step_random(self, roll=True, auto_reset=True, choice_u32=None, no_flip=False, only_player=None, walk=False):
+        """walk=True: the one-lane-per-game whole-tree walk instead of the bounded task kernels (same result)."""
         c = None
         if choice_u32 is not None:
             c = torch.as_tensor(np.asarray(choice_u32, dtype=np.uint32).view(np.int32)).to(self.device).contiguous()
-        _capi.check(self._lib.bgamd_env_step_random(self._h, self._flags(roll, auto_reset, no_flip, only_player), _ptr(c), _stream()),
-                    "step_random")
+        fn = self._lib.bgamd_env_step_random_walk if walk else self._lib.bgamd_env_step_random
+        _capi.check(fn(self._h, self._flags(roll, auto_reset, no_flip, only_player), _ptr(c), _stream()), "step_random")
         if c is not None:
             torch.cuda.current_stream().synchronize()
 

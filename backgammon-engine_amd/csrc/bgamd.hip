@@ -545,6 +545,7 @@ __global__ void legal_moves_kernel(EnvView e, const int32_t *__restrict__ player
 }
 
 #include "bg_staged_kernels.h"
+#include "bg_random_kernels.h"
 
 }  // namespace
 
@@ -566,6 +567,7 @@ struct bgamd_env {
     int device = 0;
     EnvView v{};
     StagedView sv{};
+    RandomView rv{};
     float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
     float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
@@ -701,6 +703,11 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         HIPCHK(hipMalloc(&sv.best, n * 8));
         HIPCHK(hipMalloc(&sv.tops, T_COUNT * 8));
         HIPCHK(hipMemset(sv.tops, 0, T_COUNT * 8));
+        RandomView &rv = env->rv;                    // bounded random-policy step (bg_random_kernels.h)
+        rv.tasks = sv.f; rv.cap = sv.cap_f; rv.top = &sv.tops[T_F];
+        HIPCHK(hipMalloc(&rv.task_count, (size_t)rv.cap * 4));
+        HIPCHK(hipMalloc(&rv.task_off, n * 4));
+        HIPCHK(hipMalloc(&rv.task_n, n * 4));
     }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
@@ -716,7 +723,7 @@ int bgamd_env_destroy(bgamd_env *env)
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
                     v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut,
-                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops};
+                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
     delete env;
@@ -835,10 +842,27 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
 {
     if (!env) return BGAMD_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    const long long n = env->v.n;
+    HIPCHK(hipMemsetAsync(&env->sv.tops[T_F], 0, 8, s));
     {
         KTimer t(env, s, 3);
-        hipLaunchKernelGGL(step_random_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, d_choice_u32);
+        hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags);
+        long long b = (n * 64 + 255) / 256;
+        const long long lim = (long long)env->n_cu * 8;
+        hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
+        hipLaunchKernelGGL(rnd_select_kernel, grid1(n, 64), dim3(64), 0, s, env->v, env->rv, flags, d_choice_u32);
     }
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+// the whole-tree walk (one lane per game, count pass + select pass); kept as the reference implementation of
+// the bounded kernels above -- tests compare the two
+int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream)
+{
+    if (!env) return BGAMD_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_random_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, d_choice_u32);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }

@@ -115,6 +115,8 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
  * count, value of the chosen afterstate.  The greedy step reports index and count exactly only with
  * BGAMD_WANT_INDEX; without it index is 0 and count 1 when a move was made (-1 / 0 when none was). */
 int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
+/* same result through the one-lane-per-game walk of the whole sequence tree (slow tail; cross-check) */
+int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
 int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);   /* slot 0 */
 int bgamd_env_load_weights_slot(bgamd_env *env, int slot /* 0 | 1 */, const float *h_weights);
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);

@@ -134,6 +134,21 @@ def test_random_trajectories_vs_oracle_4096(bg, O):
     assert s["games_finished"] == fin and s["candidates_raw"] == ctot and s["steps"] == n * steps
 
 
+def test_random_step_bounded_equals_walk(bg):
+    """The bounded task kernels and the whole-tree walk are two implementations of the same reference-order
+    choice: identical states, choices and sequences for 16 384 lanes over 120 steps."""
+    n = 16384
+    a, b = bg.VecGame(n, seed=123), bg.VecGame(n, seed=123)
+    for t in range(120):
+        a.step_random(); b.step_random(walk=True)
+        if t % 10 == 9:
+            la, lb = a.last_choice(), b.last_choice()
+            for k in ("chosen", "count", "seq", "seq_len"):
+                assert (_np(la[k]) == _np(lb[k])).all(), (t, k)
+    assert (_np(a.states()) == _np(b.states())).all() and (_np(a.turns()) == _np(b.turns())).all()
+    assert a.stats() == b.stats()
+
+
 def test_shard_invariance(bg):
     """lane g of shard r plays global game r*B/R + g -- results do not depend on R."""
     n, steps = 1024, 60
