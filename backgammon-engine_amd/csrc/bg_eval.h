@@ -132,6 +132,29 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
         RowDecode rd;
         decode_setup(p, h, rd);
 
+        // Block sparsity: a k-step (2 features x 32 rows) whose A column is zero in EVERY row of the tile adds
+        // exactly nothing, so it is skipped.  Rows of a tile come from one or two games and share most empty
+        // points: typically ~40 of the 96 board k-steps survive.  The executed steps stay in ascending k, so every
+        // row sees its non-zero terms in the same order as the dense chain -- results are bit-identical.
+        //   even step (n>=1 | n>=2) of (point i, side q) is live iff some row has a checker there;
+        //   odd  step (n>=3 | (n-3)/2)               is live iff some row has >= 3 there.
+        uint32_t live[4];
+        {
+            const uint32_t b0a = p[0] & PTS, b1a = p[1] & PTS, b2a = p[2] & PTS, b3a = p[3] & PTS;
+            const uint32_t b0b = p[4] & PTS, b1b = p[5] & PTS, b2b = p[6] & PTS, b3b = p[7] & PTS;
+            live[0] = b0a | b1a | b2a | b3a;            // side 0 even
+            live[1] = (b0a & b1a) | b2a | b3a;          // side 0 odd
+            live[2] = b0b | b1b | b2b | b3b;            // side 1 even
+            live[3] = (b0b & b1b) | b2b | b3b;          // side 1 odd
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) live[q] |= __shfl_xor(live[q], m, 64);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) live[q] = __builtin_amdgcn_readfirstlane(live[q]) >> 1;   // bit i = point i
+        }
+
         floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
 #define BG_MFMA4(aval, WV)                                                          \
     {                                                                                \
@@ -140,36 +163,23 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).z, acc2, 0, 0, 0);    \
         acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), (WV).w, acc3, 0, 0, 0);    \
     }
-        // two waves share each SIMD: the one in its MFMA loop must win issue arbitration over the one in
-        // its VALU-dense epilogue (priority beats age: MI355X_MICROARCH.md, two waves per SIMD, item 2)
         __builtin_amdgcn_s_setprio(2);
-        // B operands (W1 from LDS) are fetched one point (4 k-steps, 1 024 MFMA cycles) ahead of use
+        // B operands (W1 from LDS) of the NEXT point are always fetched while this point's MFMAs run (LDS
+        // bandwidth is cheap; a skipped step only wastes its 1 KB read)
         const float4 *wp = sW + lane;
         float4 wa = wp[0 * 64], wb = wp[1 * 64], wc = wp[2 * 64], wd = wp[3 * 64];
-#pragma unroll 2
         for (int i = 0; i < 24; ++i) {
+            const int nb = (4 * i + 4) * 64;
+            const float4 na = wp[nb], nbb = wp[nb + 64], nc = wp[nb + 128], nd = wp[i < 23 ? nb + 192 : nb + 128];
             const float a0 = decode_even(rd, 0, i);
             const float a1 = decode_odd(rd, 0, i);
             const float a2 = decode_even(rd, 1, i);
             const float a3 = decode_odd(rd, 1, i);
-            // steps 4i+4 .. 4i+7 (i == 23: steps 96..98 and a dummy in-range read)
-            const int nb = (4 * i + 4) * 64;
-            const float4 na = wp[nb], nbb = wp[nb + 64], nc = wp[nb + 128], nd = wp[i < 23 ? nb + 192 : nb + 128];
-            BG_MFMA4(a0, wa);
-            BG_MFMA4(a1, wb);
-            BG_MFMA4(a2, wc);
-            BG_MFMA4(a3, wd);
+            if ((live[0] >> i) & 1u) BG_MFMA4(a0, wa);
+            if ((live[1] >> i) & 1u) BG_MFMA4(a1, wb);
+            if ((live[2] >> i) & 1u) BG_MFMA4(a2, wc);
+            if ((live[3] >> i) & 1u) BG_MFMA4(a3, wd);
             wa = na; wb = nbb; wc = nc; wd = nd;
-            // pin the schedule: the 4 LDS reads of the NEXT point first, then this point's 16 MFMAs with
-            // the decode VALU of the following k-step in their shadow (cdna_hip_programming.md T19)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         BG_MFMA4(rd.tail[0], wa);
         BG_MFMA4(rd.tail[1], wb);
