@@ -20,7 +20,7 @@ constexpr int N_IN = 198, N_HID = 128;
 constexpr int N_PARAMS = N_HID * N_IN + N_HID + N_HID + 1;
 constexpr int K_STEPS = N_IN / 2;                  // 99
 constexpr int EVAL_LDS_BYTES = K_STEPS * 64 * 16;  // 101 376
-constexpr int EVAL_THREADS = 512;                  // 8 waves per CU: two per SIMD share the MFMA pipe and hide each other's stalls
+constexpr int EVAL_THREADS = 768;                  // 12 waves per CU (3 per SIMD): block-sparse tiles leave the MFMA pipe ~50 % busy, more waves fill it
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
