@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
 // surviving copy has the smaller key prefix, so every afterstate keeps its smallest-key representative.
 enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
 constexpr int STAGE_THREADS = 512;
-constexpr int STAGE_CAP = 2048;            // staged rows per round (40 B each, SoA)
-constexpr int STAGE_T = 4096;              // hash slots
+// staged rows per round (40 B each, SoA): the doubles plies get the wide de-dup window (their duplicates
+// multiply downstream), the leaf stage the narrow one (three resident blocks per CU instead of one)
+__host__ __device__ constexpr int stage_cap(int mode) { return mode == 3 ? 1024 : 2048; }
+__host__ __device__ constexpr int stage_blocks_per_cu(int mode) { return 160 * 1024 / (stage_cap(mode) * 50 + 256); }
 constexpr uint32_t STAGE_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 constexpr uint32_t INFO_SELF = 0x40000000u;   // staged entry is the node itself (stuck), not a child
@@ -105,6 +107,8 @@ constexpr uint32_t INFO_SELF = 0x40000000u;   // staged entry is the node itself
 template <int MODE>
 __global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedView sv)
 {
+    constexpr int STAGE_CAP = stage_cap(MODE);
+    constexpr int STAGE_T = 2 * STAGE_CAP;         // hash slots
     __shared__ uint32_t s_row[10][STAGE_CAP];  // p0..p7, game, key | flags
     __shared__ uint32_t s_tab[STAGE_T];
     __shared__ uint16_t s_pos[STAGE_CAP];
