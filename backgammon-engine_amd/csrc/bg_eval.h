@@ -171,14 +171,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
         for (int i = 0; i < 24; ++i) {
             const int nb = (4 * i + 4) * 64;
             const float4 na = wp[nb], nbb = wp[nb + 64], nc = wp[nb + 128], nd = wp[i < 23 ? nb + 192 : nb + 128];
+            // the cheap even-step operands are formed up front (in the shadow of the previous point's MFMAs);
+            // the 9-instruction odd-step decode only where that step is live (it rarely is: >= 3 checkers)
             const float a0 = decode_even(rd, 0, i);
-            const float a1 = decode_odd(rd, 0, i);
             const float a2 = decode_even(rd, 1, i);
-            const float a3 = decode_odd(rd, 1, i);
             if ((live[0] >> i) & 1u) BG_MFMA4(a0, wa);
-            if ((live[1] >> i) & 1u) BG_MFMA4(a1, wb);
+            if ((live[1] >> i) & 1u) { const float a1 = decode_odd(rd, 0, i); BG_MFMA4(a1, wb); }
             if ((live[2] >> i) & 1u) BG_MFMA4(a2, wc);
-            if ((live[3] >> i) & 1u) BG_MFMA4(a3, wd);
+            if ((live[3] >> i) & 1u) { const float a3 = decode_odd(rd, 1, i); BG_MFMA4(a3, wd); }
             wa = na; wb = nbb; wc = nc; wd = nd;
         }
         BG_MFMA4(rd.tail[0], wa);
