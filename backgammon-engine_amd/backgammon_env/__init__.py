@@ -222,10 +222,10 @@ class VecGame:
         return {"chosen": ch, "count": cnt, "seq": sq, "seq_len": ln, "value": val}
 
     def stats(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 10)()
         _capi.check(self._lib.bgamd_env_stats(self._h, out), "stats")
         k = ("steps", "games_finished", "p1_wins", "candidates_raw", "rows_evaluated", "error_flags",
-             "leaf_parent_nodes", "doubles_inner_nodes")
+             "leaf_parent_nodes", "doubles_inner_nodes", "ksteps_executed")
         return dict(zip(k, [int(v) for v in out]))
 
     def reset_stats(self):

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wl, const float *__restrict__ b1, const float *__restrict__ w2,
     const float *__restrict__ b2p, float *__restrict__ values, const uint2 *__restrict__ info,
-    unsigned long long *__restrict__ best)
+    unsigned long long *__restrict__ best, unsigned long long *__restrict__ ksteps_counter)
 {
     extern __shared__ float4 sW[];
     float *sRed = reinterpret_cast<float *>(sW + K_STEPS * 64) + (threadIdx.x >> 6) * EVAL_RED_FLOATS;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     for (int c = 0; c < 4; ++c) { b1s[c] = NL2E * b1[32 * c + r]; w2v[c] = w2[32 * c + r]; }
     const float b2 = *b2p;
 
+    uint32_t ksteps = 0;                                  // executed k-steps of this wave (roofline report)
     // software pipeline: the next tile's row is in flight while this tile is in the MFMA loop
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
     if (wave < n_tiles && wave * 32 + r < n_rows) { nx0 = rows[2 * (wave * 32 + r)]; nx1 = rows[2 * (wave * 32 + r) + 1]; }
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) live[q] = __builtin_amdgcn_readfirstlane(live[q]) >> 1;   // bit i = point i
+            ksteps += (uint32_t)(__popc(live[0]) + __popc(live[1]) + __popc(live[2]) + __popc(live[3]) + 3);
         }
 
         floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
@@ -226,6 +228,13 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
             }
         }
     }
+    // one global atomic per block: a per-tile atomic on one address would serialise the whole launch (~10 ns each)
+    __shared__ unsigned int s_ksteps;
+    if (threadIdx.x == 0) s_ksteps = 0;
+    __syncthreads();
+    if (lane == 0 && ksteps) atomicAdd(&s_ksteps, ksteps);
+    __syncthreads();
+    if (ksteps_counter && threadIdx.x == 0 && s_ksteps) atomicAdd(ksteps_counter, (unsigned long long)s_ksteps);
 }
 
 // ================================ bf16 speed mode ================================================

@@ -23,7 +23,7 @@ using namespace bg;
 
 namespace {
 
-enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_FNODES, C_DNODES, C_COUNT };
+enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_FNODES, C_DNODES, C_KSTEPS, C_COUNT };
 enum { ERRF_ARENA = 1, ERRF_STATE = 2 };
 constexpr uint32_t META_FINISHED = 1u << 12;
 
@@ -903,7 +903,8 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
-                           (const float4 *)env->d_wl[slot], b1, w2, b2, values, info, best);
+                           (const float4 *)env->d_wl[slot], b1, w2, b2, values, info, best,
+                           n_rows_ptr ? &env->v.counters[C_KSTEPS] : (unsigned long long *)nullptr);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -954,7 +955,7 @@ int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, i
     return BGAMD_OK;
 }
 
-int bgamd_env_stats(bgamd_env *env, uint64_t h_out[8])
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[10])
 {
     if (!env || !h_out) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(env->device));
@@ -963,7 +964,7 @@ int bgamd_env_stats(bgamd_env *env, uint64_t h_out[8])
     HIPCHK(hipMemcpy(h, env->v.counters, sizeof h, hipMemcpyDeviceToHost));
     h_out[0] = h[C_STEPS]; h_out[1] = h[C_FINISHED]; h_out[2] = h[C_P1WINS];
     h_out[3] = h[C_CAND_RAW]; h_out[4] = h[C_ROWS_EVAL]; h_out[5] = h[C_ERR];
-    h_out[6] = h[C_FNODES]; h_out[7] = h[C_DNODES];
+    h_out[6] = h[C_FNODES]; h_out[7] = h[C_DNODES]; h_out[8] = h[C_KSTEPS]; h_out[9] = 0;
     return check_err_flags(env, h[C_ERR]);
 }
 

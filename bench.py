@@ -157,7 +157,7 @@ def main():
     kt = env.kernel_times() if not a.no_kernel_timing else None
     env.time_kernels(False)
     st = env.stats()
-    tot, t_max = aggregate({k: st[k] for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated")},
+    tot, t_max = aggregate({k: st[k] for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated", "ksteps_executed")},
                            elapsed, device=dev)
     if rank != 0:
         if world > 1:
@@ -189,10 +189,18 @@ def main():
         # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
         leaves_gbs = (fn_l * 52 + u_l * 40) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
         expand_gbs = (steps_l * 52 + (fn_l + 2 * dn_l) * 8 + dn_l * 44) / (per["expand"] * 1e-3) / 1e9 if per["expand"] else 0.0
+        # executed MFMA work (fp32 kernel): k-steps that are zero for a whole 32-row tile are skipped
+        ks_l = st.get("ksteps_executed", 0) / nl
+        exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32" else None
         roofs = {
             "eval": {"kernel": "eval_rows_%s_kernel" % a.precision, "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK[a.precision],
                      "unit": "TFLOP/s", "frac": round(eval_tf / PEAK[a.precision], 4), "traffic": None, "avg_ms": round(per["eval"], 4),
-                     "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)},
+                     "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
+                     "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
+                     "executed_frac_of_peak": round(exec_tf / PEAK[a.precision], 4) if exec_tf else None,
+                     "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
+                     "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d); frac can exceed 1 because the "
+                             "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"},
             "leaves": {"kernel": "leaves_kernel", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
             "expand": {"kernel": "roots_kernel+expand_kernel<1,2>", "bound": "hbm", "achieved": round(expand_gbs, 2),

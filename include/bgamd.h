@@ -124,8 +124,9 @@ int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, i
                           int32_t *d_seq_len, float *d_value, void *stream);
 
 /* counters since create/reset_stats (synchronises): [steps, games_finished, p1_wins, candidates_raw,
- * rows_evaluated, error_flags, leaf_parent_nodes, doubles_inner_nodes] */
-int bgamd_env_stats(bgamd_env *env, uint64_t h_out[8]);
+ * rows_evaluated, error_flags, leaf_parent_nodes, doubles_inner_nodes, ksteps_executed (fp32 value net:
+ * 32-row x 2-feature MFMA steps actually issued, of 99 per tile), reserved] */
+int bgamd_env_stats(bgamd_env *env, uint64_t h_out[10]);
 int bgamd_env_reset_stats(bgamd_env *env, void *stream);
 
 /* single-checker surface for lane-wise moves: Game::tryMove (game.cpp:573-663) and
