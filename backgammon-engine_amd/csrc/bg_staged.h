@@ -1,10 +1,10 @@
 // bg_staged.h -- load-balanced greedy step: the turn-sequence tree of every game is expanded one
 // ply per kernel ("node" = game + move prefix), so no lane ever walks more than one node:
 //
-//   roots_kernel    lane per game : roll, first-ply moves      -> D1 (doubles) / F (leaf parents)
-//   expand_kernel   lane per node : doubles ply 2 and 3        -> D2 / F
-//   leaves_kernel   lane per F node: <= 15 afterstates each, staged per workgroup, de-duplicated
-//                   through an LDS hash (exact 256-bit compare)  -> unique rows + (game, key)
+//   roots_kernel         lane per game : roll, first-ply moves      -> D1 (doubles) / F (leaf parents)
+//   stage_kernel<PLY2/3> lane per node : doubles ply 2 and 3, children staged in LDS and de-duplicated -> D2 / F
+//   stage_kernel<LEAF>   lane per F node: <= 15 afterstates each, staged in LDS, de-duplicated through an
+//                        LDS hash (exact 256-bit compare)      -> unique rows + (game, key)
 //   eval kernel     (bg_eval.h)   : value per unique row, atomicMax of (value, ~key) per game
 //   apply_kernel    lane per game : decode the winning key, replay its <= 4 moves, terminal/reset
 //
@@ -67,15 +67,13 @@ __device__ __forceinline__ unsigned long long block_alloc(unsigned long long *to
 struct StagedView {
     Node *d1, *d2, *f;                    // node lists
     long long cap_d1, cap_d2, cap_f;
-    uint4 *raw_rows;                      // per-workgroup staging of all leaves (2 x uint4 each)
-    uint2 *raw_info;                      // (game, key | turn<<31)
     uint4 *u_rows;                        // unique rows
     uint2 *u_info;
     long long cap_rows;
     unsigned long long *best;             // [n] (ordered value bits << 32) | ~key ; 0 = no candidate
     unsigned long long *tops;             // [T_COUNT]
 };
-enum { T_D1 = 0, T_D2, T_F, T_RAW, T_U, T_COUNT };
+enum { T_D1 = 0, T_D2, T_F, T_U, T_COUNT };
 
 __device__ __forceinline__ uint32_t hash_row(const uint32_t (&p)[8], uint32_t game)
 {

@@ -6,7 +6,8 @@
 //   ply, episode uint32[n]  Philox counter words (game_id = lane_offset + lane + episode*lane_stride)
 //   arena    uint4[2*cap]   candidate afterstates, 32 B rows, reference order inside a lane's segment
 //   values   float[cap]     value-net output per row
-// The step is: emit (count pass, wave-level bump allocation, emit pass) -> eval (MFMA) -> select/apply.
+// Greedy step: roots -> stage<PLY2> -> stage<PLY3> -> stage<LEAF> (bg_staged_kernels.h) -> eval (bg_eval.h) -> apply.
+// Random step: rnd_tasks -> rnd_count -> rnd_select (bg_random_kernels.h).  emit_kernel serves the ordered enumerate API.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -232,55 +233,6 @@ __global__ __launch_bounds__(64) void emit_kernel(EnvView e, int flags, int with
         e.cand_cnt[g] = C;
         if ((flags & BGAMD_ROLL) && c.live) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
     }
-}
-
-// ---- select + apply: argmax / argmin over each lane's segment, cooperative over the wave -------
-__global__ __launch_bounds__(64) void select_apply_kernel(EnvView e, int flags, float epsilon, int have_seq)
-{
-    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
-    const int lane = threadIdx.x;
-    LaneCtx c;
-    lane_begin(e, g, flags & ~BGAMD_ROLL, c);      // dice were stored by emit_kernel
-    const uint32_t cnt = (g < e.n && c.live) ? e.cand_cnt[g] : 0u;
-    const uint32_t off = (g < e.n) ? e.cand_off[g] : 0u;
-    unsigned long long mykey = 0;
-    for (int j = 0; j < 64; ++j) {
-        const uint32_t cj = __shfl(cnt, j, 64);
-        if (cj == 0) continue;
-        const uint32_t oj = __shfl(off, j, 64);
-        const int tj = __shfl(c.turn, j, 64);
-        unsigned long long best = 0;
-        for (uint32_t i = lane; i < cj; i += 64) {
-            uint32_t bits = __float_as_uint(e.values[(unsigned long long)oj + i]);
-            bits = tj ? ~bits : bits;                   // P2 minimises (model.py:212-213)
-            const unsigned long long key = ((unsigned long long)bits << 32) | (uint32_t)~i;   // first index wins ties
-            best = key > best ? key : best;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const uint32_t lo = __shfl_xor((uint32_t)best, m, 64), hi = __shfl_xor((uint32_t)(best >> 32), m, 64);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            best = o > best ? o : best;
-        }
-        if (lane == j) mykey = best;
-    }
-    int32_t chosen = -1;
-    uint32_t cseq = 0;
-    float cval = 0.0f;
-    if (cnt > 0) {
-        uint32_t idx = ~(uint32_t)mykey;
-        if (epsilon > 0.0f && (float)(c.x.w >> 8) * (1.0f / 16777216.0f) < epsilon)
-            idx = (uint32_t)(((unsigned long long)c.x.z * cnt) >> 32);      // explore (model.py:205-206)
-        const unsigned long long r = (unsigned long long)off + idx;
-        const uint4 u0 = e.rows[2 * r], u1 = e.rows[2 * r + 1];
-        c.p[0] = u0.x & ~TURN_BIT; c.p[1] = u0.y; c.p[2] = u0.z; c.p[3] = u0.w;
-        c.p[4] = u1.x; c.p[5] = u1.y; c.p[6] = u1.z; c.p[7] = u1.w;
-        chosen = (int32_t)idx;
-        cval = e.values[r];
-        if (have_seq) cseq = e.seqs[r] | (c.turn ? (1u << 29) : 0u);
-    }
-    if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.chosen_val[g] = cval; }
-    finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
 }
 
 // ---- small state kernels ---------------------------------------------------------------------------
@@ -696,8 +648,6 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         HIPCHK(hipMalloc(&sv.d1, (size_t)sv.cap_d1 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.d2, (size_t)sv.cap_d2 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
-        sv.raw_rows = v.rows;                       // the ordered arena doubles as staging
-        HIPCHK(hipMalloc(&sv.raw_info, (size_t)cap * sizeof(uint2)));
         HIPCHK(hipMalloc(&sv.u_rows, (size_t)cap * 32));
         HIPCHK(hipMalloc(&sv.u_info, (size_t)cap * sizeof(uint2)));
         HIPCHK(hipMalloc(&sv.best, n * 8));
@@ -723,7 +673,7 @@ int bgamd_env_destroy(bgamd_env *env)
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
                     v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut,
-                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.raw_info, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
+                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
     delete env;

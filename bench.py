@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
     ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
                     help="value-net arithmetic; f32 is the parity mode (1e-5 vs the reference) and the headline")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -120,17 +121,21 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend)
 
     import backgammon_env as bg
     from backgammon_env.shard import aggregate, shard_for_rank
 
     w = np.fromfile(os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32"), dtype=np.float32)
     off, stride = shard_for_rank(rank, world, a.games)
-    env = bg.VecGame(a.games, device=local_rank, seed=SEED, lane_offset=off, lane_stride=stride,
+    env = bg.VecGame(a.games, device=dev_index, seed=SEED, lane_offset=off, lane_stride=stride,
                      arena_rows=a.games * 512)
     env.load_weights(w)
     prec = bg.BF16 if a.precision == "bf16" else bg.F32
@@ -158,7 +163,7 @@ def main():
     env.time_kernels(False)
     st = env.stats()
     tot, t_max = aggregate({k: st[k] for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated", "ksteps_executed")},
-                           elapsed, device=dev)
+                           elapsed, device=dev if a.dist_backend == "nccl" else None)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
