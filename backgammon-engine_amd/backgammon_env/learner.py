@@ -54,9 +54,16 @@ class TDLambdaLearner:
         eW1, eb1, eW2, eb2 = self._split(e)
         sq = torch.zeros((), dtype=torch.float64, device=dev)
         cnt = torch.zeros((), dtype=torch.int64, device=dev)
-        Tmax = int(lengths.max().item()) if G else 0
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        for t in range(min(T, Tmax)):
+        n_steps = torch.tensor([min(T, int(lengths.max().item()) if G else 0)], dtype=torch.int64, device=dev)
+        if distributed:                      # every rank must issue the same number of all-reduces
+            dist.all_reduce(n_steps, op=dist.ReduceOp.MAX, group=group)
+        for t in range(int(n_steps.item())):
+            if t >= T:                       # this rank's log is shorter: it still joins the collective
+                upd = torch.zeros(25601, dtype=dt, device=dev)
+                dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)
+                self.theta.add_(upd)
+                continue
             active = (lengths > t)
             terminal = (lengths == t + 1)
             W1, b1, W2, b2 = self._split(self.theta)
