@@ -42,10 +42,14 @@ class TDLambdaLearner:
         h = torch.sigmoid(X @ W1.T + b1)
         return torch.sigmoid(h @ W2 + b2), h
 
-    def replay(self, X, lengths, p1_won, group=None):
+    def replay(self, X, lengths, p1_won, group=None, batch_scale: float = 1.0):
         """X: float [T, G, 198] encodings of the pre-move states of every turn (turn bit = side to move),
         lengths: int [G] number of recorded turns per game, p1_won: bool/int [G].
-        Applies the lock-step TD(λ) updates in place; returns the summed squared TD error and count."""
+        Applies the lock-step TD(λ) updates in place; returns the summed squared TD error and count.
+        batch_scale multiplies every game's update.  1.0 = the plain sum, which matches the reference to first
+        order for rounds of the reference's size (round_size = workers <= 24, train.py:307-312); a round of
+        tens of thousands of games moves the weights that many times further per step, so large rounds want
+        batch_scale ~ 24 / G (the update of an average reference-sized round)."""
         T, G = X.shape[0], X.shape[1]
         dev, dt = self.theta.device, self.theta.dtype
         lengths = torch.as_tensor(lengths, device=dev).long()
@@ -79,11 +83,13 @@ class TDLambdaLearner:
             db1 = (g[:, None] * W2[None, :]) * h * (1 - h)
             lam = self.lambda_decay
             eb2.mul_(lam).add_(g[:, None])
-            eW2.mul_(lam).add_(g[:, None] * h)
+            eW2.mul_(lam).addcmul_(g[:, None], h)
             eb1.mul_(lam).add_(db1)
-            eW1.mul_(lam).add_(db1[:, :, None] * x[:, None, :])
+            # e_W1 <- lam * e_W1 + db1 (x) x as ONE batched rank-1 update: a single read+write pass over the
+            # G x 128 x 198 traces (the traffic that bounds the learner, SURVEY hard part 5)
+            eW1.baddbmm_(db1[:, :, None], x[:, None, :], beta=lam, alpha=1.0)
             # α·δ is formed in float64 by the reference (python floats, train.py:147) before the fp32 multiply
-            coef = (self.learning_rate * delta.double()).to(dt)
+            coef = (self.learning_rate * batch_scale * delta.double()).to(dt)
             upd = coef @ e                                          # Σ_g (α δ_g) e_g : [25601]
             if distributed:
                 dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)   # the ONE collective per training step
