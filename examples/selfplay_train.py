@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end rehearsal of configs 4/5 on ONE GPU: batched self-play with the turn log, lock-step TD(λ)
+replay (PyTorch-ROCm), weights back into the env; win rate against a uniformly random mover before and after.
+Not the reference's training CLI (out of scope) -- a 60-line demonstration that the pieces compose.
+
+    python examples/selfplay_train.py --games 512 --rounds 120
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.join(ROOT, "backgammon-engine_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import backgammon_env as bg  # noqa: E402
+from backgammon_env.arena import head_to_head  # noqa: E402
+from backgammon_env.learner import TDLambdaLearner, play_round  # noqa: E402
+
+
+def xavier_init(seed=0):
+    """model.py:55-61: xavier_uniform(gain=0.1) weights, zero biases."""
+    g = torch.Generator().manual_seed(seed)
+    def xu(fan_out, fan_in):
+        a = 0.1 * (6.0 / (fan_in + fan_out)) ** 0.5
+        return (torch.rand((fan_out, fan_in), generator=g) * 2 - 1) * a
+    return torch.cat([xu(128, 198).flatten(), torch.zeros(128), xu(1, 128).flatten(), torch.zeros(1)]).numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=512, help="games per round (one per lane)")
+    ap.add_argument("--rounds", type=int, default=120)
+    ap.add_argument("--eps", type=float, default=0.05)
+    a = ap.parse_args()
+    env, arena = bg.VecGame(a.games, seed=1), bg.VecGame(1024, seed=2)
+    L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
+    print("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
+    t0, turns = time.time(), 0
+    for r in range(a.rounds):
+        L.update_learning_params(r * a.games)
+        env.load_weights(L.theta.cpu().numpy())
+        rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=a.eps)
+        sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, batch_scale=min(1.0, 24.0 / a.games))
+        turns += cnt
+        if r % 20 == 19:
+            print(f"round {r + 1}: {(r + 1) * a.games} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
+                  f"{turns / (time.time() - t0):.0f} turns/s", flush=True)
+    print("after: vs random", head_to_head(arena, L.theta.cpu().numpy(), None), flush=True)
+
+
+if __name__ == "__main__":
+    main()
