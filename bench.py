@@ -130,6 +130,12 @@ def main():
         else:
             dist.init_process_group(a.dist_backend)
 
+    if not os.path.exists(os.path.join(ROOT, "backgammon-engine_amd", "libbgamd.so")):
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     import backgammon_env as bg
     from backgammon_env.shard import aggregate, shard_for_rank
 
