@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (AUTO_RESET, BF16, F32, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
+from ._capi import (AUTO_RESET, BF16, F16X2, F32, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
                     BgamdError)
 
 __all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed"]

@@ -376,6 +376,166 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_bf16_kernel(
     }
 }
 
+// ================================ f16 x 2 split: fp32-grade values on the fast matrix pipe ================
+// W1 = hi + lo with hi = f16(W1), lo = f16(W1 - hi): 22 mantissa bits, |error| <= 2^-22 |w| + 3e-8.  Every
+// feature is exact in f16 except off/15, which is fed as its own hi + lo pair, so each product is exact in
+// fp32 and the only rounding is the fp32 accumulation -- the same error class as the f32 MFMA kernel, at two
+// v_mfma_f32_32x32x16_f16 per (K-step, column tile) instead of sixteen-times-slower f32 MFMAs, and on a pipe
+// that runs beside the VALU.  Same K layout as the bf16 kernel (one K-step = two board points); the tail step
+// is [turn0, turn1, bar1/2, bar2/2, off1.hi, off1.lo, off2.hi, off2.lo].
+constexpr int EVAL16X2_W_BYTES = 2 * EVAL16_W_BYTES;               // 106 496
+constexpr int EVAL16X2_LDS_TOTAL = EVAL16X2_W_BYTES + EVAL16_LUT_BYTES + (EVAL_THREADS / 64) * EVAL_RED_FLOATS * 4;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ inline uint16_t f16_bits(_Float16 h)
+{
+    union { _Float16 h; uint16_t u; } c{h};
+    return c.u;
+}
+
+// Wl[part][s][c][l][j], part 0 = hi, 1 = lo; tail feature map above
+inline void relayout_w1_f16x2(const float *w1, uint16_t *wl)
+{
+    static const int tail_map[8] = {192, 193, 194, 195, 196, 196, 197, 197};
+    for (int s = 0; s < K16_STEPS; ++s)
+        for (int c = 0; c < 4; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    int f = 16 * s + 8 * (l >> 5) + j;
+                    if (s == 12) f = (l >> 5) == 0 ? tail_map[j] : -1;
+                    float w = f >= 0 && f < N_IN ? w1[(32 * c + (l & 31)) * N_IN + f] : 0.0f;
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)(w - (float)hi);
+                    const size_t o = (((size_t)s * 4 + c) * 64 + l) * 8 + j;
+                    wl[o] = f16_bits(hi);
+                    wl[(size_t)K16_STEPS * 4 * 64 * 8 + o] = f16_bits(lo);
+                }
+}
+// LUT[n] = f16 x4 {n>=1, n>=2, n>=3, (n-3)/2 if n>=4}
+inline void make_count_lut_f16(uint32_t *lut /*[16][2]*/)
+{
+    for (int n = 0; n < 16; ++n) {
+        const uint16_t one = f16_bits((_Float16)1.0f);
+        const uint16_t e0 = n >= 1 ? one : 0, e1 = n >= 2 ? one : 0, e2 = n >= 3 ? one : 0;
+        const uint16_t e3 = n >= 4 ? f16_bits((_Float16)(0.5f * (float)(n - 3))) : 0;
+        lut[2 * n] = (uint32_t)e0 | ((uint32_t)e1 << 16);
+        lut[2 * n + 1] = (uint32_t)e2 | ((uint32_t)e3 << 16);
+    }
+}
+
+__global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f16x2_kernel(
+    const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
+    unsigned long long *__restrict__ rows_eval_counter, const uint4 *__restrict__ wl16, const uint2 *__restrict__ lut,
+    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2p, float *__restrict__ values,
+    const uint2 *__restrict__ info, unsigned long long *__restrict__ best)
+{
+    extern __shared__ uint4 sW16[];
+    constexpr int PART = K16_STEPS * 4 * 64;                     // uint4 entries per weight part
+    uint2 *sLut = reinterpret_cast<uint2 *>(sW16 + 2 * PART);
+    float *sRed = reinterpret_cast<float *>(sLut + 16) + (threadIdx.x >> 6) * EVAL_RED_FLOATS;
+    for (int i = threadIdx.x; i < 2 * PART; i += EVAL_THREADS) sW16[i] = wl16[i];
+    if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+
+    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
+    const long long n_tiles = (n_rows + 31) >> 5;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const long long wave = (long long)blockIdx.x * (EVAL_THREADS / 64) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (EVAL_THREADS / 64);
+    constexpr float NL2E = -1.44269504088896340736f;
+    float b1s[4], w2v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { b1s[c] = NL2E * b1[32 * c + r]; w2v[c] = w2[32 * c + r]; }
+    const float b2 = *b2p;
+
+    uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
+    if (wave < n_tiles && wave * 32 + r < n_rows) { nx0 = rows[2 * (wave * 32 + r)]; nx1 = rows[2 * (wave * 32 + r) + 1]; }
+
+    for (long long tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t p[8] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
+        {
+            const long long nrow = (tile + n_waves) * 32 + r;
+            nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0);
+            if (nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; }
+        }
+        const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+        floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+        const uint4 *wp = sW16 + lane;
+#define BG_F16X2_STEP(AFRAG, S)                                                                         \
+    {                                                                                                   \
+        union { uint4 u; f16x8 v; } w0, w1, w2r, w3, l0, l1, l2, l3;                                     \
+        w0.u = wp[((S) * 4 + 0) * 64]; w1.u = wp[((S) * 4 + 1) * 64];                                     \
+        w2r.u = wp[((S) * 4 + 2) * 64]; w3.u = wp[((S) * 4 + 3) * 64];                                    \
+        l0.u = wp[PART + ((S) * 4 + 0) * 64]; l1.u = wp[PART + ((S) * 4 + 1) * 64];                       \
+        l2.u = wp[PART + ((S) * 4 + 2) * 64]; l3.u = wp[PART + ((S) * 4 + 3) * 64];                       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), l0.v, acc0, 0, 0, 0);                      \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), l1.v, acc1, 0, 0, 0);                      \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), l2.v, acc2, 0, 0, 0);                      \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), l3.v, acc3, 0, 0, 0);                      \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), w0.v, acc0, 0, 0, 0);                      \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), w1.v, acc1, 0, 0, 0);                      \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), w2r.v, acc2, 0, 0, 0);                     \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16((AFRAG), w3.v, acc3, 0, 0, 0);                      \
+    }
+#pragma unroll 4
+        for (int s = 0; s < 12; ++s) {
+            const int pos = 2 * s + h + 1;                       // board point 2s+h  ->  bit position +1
+            const uint2 e0 = sLut[count_at(sa, pos)], e1 = sLut[count_at(sb, pos)];
+            union { uint4 u; f16x8 v; } a;
+            a.u = make_uint4(e0.x, e0.y, e1.x, e1.y);
+            BG_F16X2_STEP(a.v, s);
+        }
+        {   // step 12: turn, bar/2, and off/15 as hi + lo halves, on the h == 0 lanes
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            const uint32_t one = 0x3C00u;
+            const uint32_t t0 = turn == 0 ? one : 0u, t1 = turn == 0 ? 0u : one;
+            const uint32_t bar1 = f16_bits((_Float16)(0.5f * (float)count_at(sa, 0))), bar2 = f16_bits((_Float16)(0.5f * (float)count_at(sb, 25)));
+            const float o1 = (float)count_at(sa, 25) / 15.0f, o2 = (float)count_at(sb, 0) / 15.0f;
+            const _Float16 o1h = (_Float16)o1, o2h = (_Float16)o2;
+            const uint32_t o1l = f16_bits((_Float16)(o1 - (float)o1h)), o2l = f16_bits((_Float16)(o2 - (float)o2h));
+            union { uint4 u; f16x8 v; } a;
+            a.u = h ? make_uint4(0, 0, 0, 0)
+                    : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), (uint32_t)f16_bits(o1h) | (o1l << 16), (uint32_t)f16_bits(o2h) | (o2l << 16));
+            BG_F16X2_STEP(a.v, 12);
+        }
+#undef BG_F16X2_STEP
+        float part[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float s0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc0[j], NL2E, b1s[0])));
+            const float s1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc1[j], NL2E, b1s[1])));
+            const float s2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc2[j], NL2E, b1s[2])));
+            const float s3 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc3[j], NL2E, b1s[3])));
+            part[j] = w2v[0] * s0 + w2v[1] * s1 + w2v[2] * s2 + w2v[3] * s3;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sRed[r * EVAL_RED_STRIDE + 8 * q + 4 * h + j] = part[4 * q + j];
+        __builtin_amdgcn_wave_barrier();
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sum += sRed[(16 * h + c) * EVAL_RED_STRIDE + r];
+        sum += __shfl_xor(sum, 32, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) {
+            const long long orow = tile * 32 + r;
+            if (orow < n_rows) {
+                const float v = fast_sigmoid(sum + b2);
+                values[orow] = v;
+                if (info) {
+                    const uint2 inf = info[orow];
+                    uint32_t bits = __float_as_uint(v);
+                    bits = (inf.y >> 31) ? ~bits : bits;
+                    atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
+                }
+            }
+        }
+    }
+}
+
 // Stand-alone encoder (the reference's _encode_states_np surface): rows -> float[n][198]
 __global__ void encode_rows_kernel(const uint4 *__restrict__ rows, long long n, float *__restrict__ out)
 {

@@ -523,7 +523,9 @@ struct bgamd_env {
     float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
     float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
+    uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
     uint2 *d_lut = nullptr;                // count -> 4 bf16 features
+    uint2 *d_lut16 = nullptr;              // count -> 4 f16 features
     bool has_weights[2] = {false, false};
     int n_cu = 256;
     // kernel timing
@@ -635,7 +637,10 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
         HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
+        HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
     }
+    HIPCHK(hipMalloc(&env->d_lut16, EVAL16_LUT_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16X2_LDS_TOTAL));
     HIPCHK(hipMalloc(&env->d_lut, EVAL16_LUT_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16_LDS_TOTAL));
     {   // staged greedy step (bg_staged.h): node lists, per-workgroup staging, unique arena
@@ -672,7 +677,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -834,6 +839,11 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     make_count_lut(lut);
     HIPCHK(hipMemcpy(env->d_wl16[slot], wl16.data(), EVAL16_W_BYTES, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(env->d_lut, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
+    std::vector<uint16_t> wx2((size_t)2 * K16_STEPS * 4 * 64 * 8);
+    relayout_w1_f16x2(h_weights, wx2.data());
+    make_count_lut_f16(lut);
+    HIPCHK(hipMemcpy(env->d_wlx2[slot], wx2.data(), EVAL16X2_W_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(env->d_lut16, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
     env->has_weights[slot] = true;
     return BGAMD_OK;
 }
@@ -842,9 +852,14 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
                        const uint4 *rows, float *values, const uint2 *info, unsigned long long *best, hipStream_t s)
 {
     if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
-    if (precision != BGAMD_F32 && precision != BGAMD_BF16) return BGAMD_E_INVALID;
+    if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2) return BGAMD_E_INVALID;
     const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
-    if (precision == BGAMD_BF16) {
+    if (precision == BGAMD_F16X2) {
+        KTimer t(env, s, 1);
+        hipLaunchKernelGGL(eval_rows_f16x2_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16X2_LDS_TOTAL, s, rows, n_rows_ptr,
+                           n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
+                           (const uint4 *)env->d_wlx2[slot], (const uint2 *)env->d_lut16, b1, w2, b2, values, info, best);
+    } else if (precision == BGAMD_BF16) {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_bf16_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,

@@ -54,7 +54,10 @@ enum {
     BGAMD_WEIGHTS_SLOT1 = 64  /* greedy step evaluates with weight slot 1 instead of slot 0        */
 };
 
-enum { BGAMD_F32 = 0, BGAMD_BF16 = 1 };   /* value-net arithmetic */
+/* value-net arithmetic.  F32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).  F16X2: W1 split into f16 hi + lo
+ * (22 mantissa bits), exact products, fp32 accumulation on v_mfma_f32_32x32x16_f16 -- fp32-grade values (inside
+ * the 1e-5 parity bound) on the fast matrix pipe.  BF16: single bf16 weights, speed mode outside the bound. */
+enum { BGAMD_F32 = 0, BGAMD_BF16 = 1, BGAMD_F16X2 = 2 };
 
 int bgamd_version(void);
 const char *bgamd_error_string(int code);

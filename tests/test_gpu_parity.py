@@ -266,6 +266,33 @@ def test_bf16_mode_matches_bf16_emulation(bg, golden_dir, weights):
     assert np.abs(v - g["v32"]).max() < 5e-3
 
 
+def test_f16x2_mode_is_inside_the_parity_bound(bg, O, golden_dir, weights):
+    """f16 hi+lo split of W1 on v_mfma_f32_32x32x16_f16 (exact products, fp32 accumulation): values within 1e-5 of
+    the reference PyTorch model like the f32 MFMA kernel, and the same greedy choices."""
+    g = np.load(os.path.join(golden_dir, "g5_values.npz"))
+    env = bg.VecGame(1, arena_rows=1 << 20)
+    env.load_weights(weights)
+    v = _np(env.evaluate(g["states"].astype(np.int32), g["turn"], precision=bg.F16X2))
+    print("f16x2: max |gpu - torch fp32| = %.3g, max |gpu - torch fp64| = %.3g" % (np.abs(v - g["v32"]).max(), np.abs(v - g["v64"]).max()))
+    assert np.abs(v - g["v32"]).max() < 1e-5 and np.abs(v - g["v64"]).max() < 1e-5
+    rng = np.random.RandomState(2)
+    for m in (1, 31, 32, 33, 97, 50000):
+        idx = rng.randint(0, len(g["turn"]), m)
+        vv = _np(env.evaluate(g["states"][idx].astype(np.int32), g["turn"][idx], precision=bg.F16X2))
+        assert np.abs(vv - g["v64"][idx]).max() < 1e-5, m
+    n = 4096
+    a, b = bg.VecGame(n, seed=19), bg.VecGame(n, seed=19)
+    a.load_weights(weights); b.load_weights(weights)
+    for t in range(40):
+        pre, pt = _np(b.states()), _np(b.turns())
+        a.step_greedy(auto_reset=False); b.step_greedy(auto_reset=False, precision=bg.F16X2)
+        if t % 8 == 0:
+            _check_greedy_step(O, weights, pre, pt, _np(b.dice()), _np(b.states()), range(t % 5, n, 41))
+    agree = (_np(a.states()) == _np(b.states())).all(1).mean()
+    print("f16x2 vs f32: identical boards after 40 greedy steps on %.2f %% of lanes" % (100 * agree))
+    assert agree > 0.97
+
+
 def test_bf16_mode_choice_agreement(bg, O, weights):
     """Same boards, same dice: the bf16 step picks the same afterstate as the fp32 step on most lanes and a
     near-optimal one (fp64 value within 5e-3 of the best) on all."""
