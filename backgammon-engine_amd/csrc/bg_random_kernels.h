@@ -129,9 +129,9 @@ __global__ __launch_bounds__(256) void rnd_count_kernel(EnvView e, RandomView rv
     }
 }
 
-__global__ __launch_bounds__(64) void rnd_select_kernel(EnvView e, RandomView rv, int flags, const uint32_t *__restrict__ choice)
+__global__ __launch_bounds__(256) void rnd_select_kernel(EnvView e, RandomView rv, int flags, const uint32_t *__restrict__ choice)
 {
-    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     LaneCtx c;
     lane_begin(e, g, flags & ~BGAMD_ROLL, c);            // dice were stored by rnd_tasks_kernel
     const uint32_t nT = (g < e.n && c.live) ? rv.task_n[g] : 0u;
@@ -166,6 +166,6 @@ __global__ __launch_bounds__(64) void rnd_select_kernel(EnvView e, RandomView rv
     }
     if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.cand_cnt[g] = C; e.chosen_val[g] = 0.0f; }
     const unsigned long long tot = wave_sum_u32(C);
-    if (threadIdx.x == 0 && tot) atomicAdd(&e.counters[C_CAND_RAW], tot);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&e.counters[C_CAND_RAW], tot);
     finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
 }

@@ -254,9 +254,9 @@ struct IndexVisitor {
 };
 
 // ---- apply: lane per game ------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void apply_kernel(EnvView e, StagedView sv, int flags, float epsilon)
+__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, int flags, float epsilon)
 {
-    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     LaneCtx c;
     lane_begin(e, g, flags & ~BGAMD_ROLL, c);            // dice were stored by roots_kernel
     const unsigned long long pack = (g < e.n && c.live) ? sv.best[g] : 0ull;

@@ -99,13 +99,24 @@ __device__ __forceinline__ void finish_turn(const EnvView &e, long long g, uint3
         e.meta[g] = meta_pack(turn, d1, d2, fin);
         e.ply[g] = ply; e.episode[g] = epi; e.flags[g] = oflags;
     }
+    // counters: wave sums -> one LDS word each -> ONE global atomic per block and counter (same-address global
+    // atomics retire at ~10 ns each: a per-wave atomic from 1 024 waves costs more than the kernel itself)
+    __shared__ unsigned int s_stat[3];
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    __syncthreads();
     const unsigned long long nsteps = wave_sum_u32(live ? 1u : 0u);
     const unsigned long long nfin = wave_sum_u32(oc ? 1u : 0u);
     const unsigned long long nw1 = wave_sum_u32(oc == 1 ? 1u : 0u);
     if ((threadIdx.x & 63) == 0) {
-        if (nsteps) atomicAdd(&e.counters[C_STEPS], nsteps);
-        if (nfin) atomicAdd(&e.counters[C_FINISHED], nfin);
-        if (nw1) atomicAdd(&e.counters[C_P1WINS], nw1);
+        if (nsteps) atomicAdd(&s_stat[0], (unsigned int)nsteps);
+        if (nfin) atomicAdd(&s_stat[1], (unsigned int)nfin);
+        if (nw1) atomicAdd(&s_stat[2], (unsigned int)nw1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_stat[0]) atomicAdd(&e.counters[C_STEPS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&e.counters[C_FINISHED], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&e.counters[C_P1WINS], (unsigned long long)s_stat[2]);
     }
 }
 
@@ -805,7 +816,7 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
         long long b = (n * 64 + 255) / 256;
         const long long lim = (long long)env->n_cu * 8;
         hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
-        hipLaunchKernelGGL(rnd_select_kernel, grid1(n, 64), dim3(64), 0, s, env->v, env->rv, flags, d_choice_u32);
+        hipLaunchKernelGGL(rnd_select_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags, d_choice_u32);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -904,7 +915,7 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     if (rc) return rc;
     {
         KTimer t(env, s, 2);
-        hipLaunchKernelGGL(apply_kernel, grid1(n, 64), dim3(64), 0, s, env->v, sv, flags, epsilon);
+        hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags, epsilon);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
