@@ -616,3 +616,26 @@ def test_errors_are_loud(bg, weights):
     g = bg.Game(0)
     with pytest.raises(ValueError):
         g.setGameBoard([0] * 25)
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the contract fields (metric/value/unit/..., roofline, cpu_baseline)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--burnin", "20",
+                          "--games", "8192"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 8 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["value"] > 1e6 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
