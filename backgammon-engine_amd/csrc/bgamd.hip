@@ -610,6 +610,9 @@ int bgamd_device_count(void)
     return n;
 }
 
+static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t lane_offset, uint64_t lane_stride,
+                        int64_t arena_rows);
+
 int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed, uint64_t lane_offset,
                      uint64_t lane_stride, int64_t arena_rows)
 {
@@ -623,6 +626,21 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     bgamd_env *env = new bgamd_env();
     env->device = device;
     env->n_cu = prop.multiProcessorCount;
+    int rc = env_allocate(env, n_games, seed, lane_offset, lane_stride, arena_rows);
+    if (rc == BGAMD_OK) rc = bgamd_env_reset(env, nullptr);
+    if (rc != BGAMD_OK) {                       // free whatever was allocated before the failure
+        const std::string why = g_hip_err;
+        bgamd_env_destroy(env);
+        g_hip_err = why;
+        return rc;
+    }
+    *out = env;
+    return BGAMD_OK;
+}
+
+static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t lane_offset, uint64_t lane_stride,
+                        int64_t arena_rows)
+{
     EnvView &v = env->v;
     v.n = n_games; v.seed = seed; v.lane_offset = lane_offset; v.lane_stride = lane_stride ? lane_stride : (uint64_t)n_games;
     long long cap = arena_rows > 0 ? arena_rows : n_games * 256;
@@ -677,8 +695,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
-    *out = env;
-    return bgamd_env_reset(env, nullptr);
+    return BGAMD_OK;
 }
 
 int bgamd_env_destroy(bgamd_env *env)
