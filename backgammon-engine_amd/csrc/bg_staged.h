@@ -2,8 +2,8 @@
 // ply per kernel ("node" = game + move prefix), so no lane ever walks more than one node:
 //
 //   roots_kernel         lane per game : roll, first-ply moves      -> D1 (doubles) / F (leaf parents)
-//   stage_kernel<PLY2/3> lane per node : doubles ply 2 and 3, children staged in LDS and de-duplicated -> D2 / F
-//   stage_kernel<LEAF>   lane per F node: <= 15 afterstates each, staged in LDS, de-duplicated through an
+//   stage2_kernel<PLY2/3> lane per node : doubles ply 2 and 3, children staged in LDS and de-duplicated -> D2 / F
+//   stage2_kernel<LEAF>  lane per F node: <= 15 afterstates each, staged in LDS, de-duplicated through an
 //                        LDS hash (exact 256-bit compare)      -> unique rows + (game, key)
 //   eval kernel     (bg_eval.h)   : value per unique row, atomicMax of (value, ~key) per game
 //   apply_kernel    lane per game : decode the winning key, replay its <= 4 moves, terminal/reset

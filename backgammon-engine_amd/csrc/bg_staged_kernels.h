@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
 }
 
 // ---- one ply per launch, with exact de-duplication inside the workgroup ------------------------------
-// stage_kernel<MODE>: a block takes STAGE_THREADS nodes; every node contributes its successor positions
+// stage2_kernel<MODE>: a block takes STAGE_THREADS nodes; every node contributes its successor positions
 // (<= 15: one per legal origin; a node with no legal move, or at full depth, contributes itself).  The
 // successors are staged in LDS in rounds of at most STAGE_CAP rows and de-duplicated through an LDS hash
 // (slot = the copy with the SMALLEST reference key among identical (game, 256-bit position)).  Only the
@@ -104,17 +104,24 @@ constexpr uint32_t STAGE_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 constexpr uint32_t INFO_SELF = 0x40000000u;   // staged entry is the node itself (stuck), not a child
 
+// One LANE PER SUCCESSOR: the node threads only publish their position (11 dwords in LDS) and their successor
+// count; after the scan every successor gets its own lane, which rebuilds it from the parent record, stages it and
+// inserts it into the hash in one go (a thread walking its node's <= 15 successors leaves most lanes idle).
 template <int MODE>
-__global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedView sv)
+__global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, StagedView sv)
 {
-    constexpr int STAGE_CAP = stage_cap(MODE);
-    constexpr int STAGE_T = 2 * STAGE_CAP;         // hash slots
-    __shared__ uint32_t s_row[10][STAGE_CAP];  // p0..p7, game, key | flags
-    __shared__ uint32_t s_tab[STAGE_T];
-    __shared__ uint16_t s_pos[STAGE_CAP];
-    __shared__ uint32_t s_wave[STAGE_THREADS / 64];
+    constexpr int NT = STAGE_THREADS;
+    constexpr int CAP = stage_cap(MODE);
+    constexpr int TSLOTS = 2 * CAP;
+    constexpr int NW = NT / 64;
+    __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
+    __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | SELF-less | turn<<31
+    __shared__ uint16_t s_par_of[CAP];         // successor (window slot) -> parent thread
+    __shared__ uint32_t s_row[10][CAP];
+    __shared__ uint32_t s_tab[TSLOTS];
+    __shared__ uint16_t s_pos[CAP];
+    __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
-    constexpr int NW = STAGE_THREADS / 64;
     const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
     const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
     unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
@@ -124,84 +131,88 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedV
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
-    for (unsigned long long blk = blockIdx.x; blk * STAGE_THREADS < n_in; blk += gridDim.x) {
-        const unsigned long long ni = blk * STAGE_THREADS + threadIdx.x;
+    for (unsigned long long blk = blockIdx.x; blk * NT < n_in; blk += gridDim.x) {
+        const unsigned long long ni = blk * NT + threadIdx.x;
         const bool valid = ni < n_in;
-        Node nd{0u, 0u};
-        NodeState s;
-        uint32_t m0 = 0;
-        int die = 1;
-        if (valid) {
-            nd = in[ni];
-            node_state(e, nd, s);
-            die = (s.len & 1) ? s.dB : s.dA;
-            if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
+        uint32_t cnt = 0;
+        {
+            Node nd{0u, 0u};
+            NodeState s;
+            uint32_t m0 = 0;
+            int die = 1;
+            if (valid) {
+                nd = in[ni];
+                node_state(e, nd, s);
+                die = (s.len & 1) ? s.dB : s.dA;
+                if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
+                cnt = m0 ? (uint32_t)__popc(m0) : 1u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s_par_plane[k][threadIdx.x] = s.own.b[k]; s_par_plane[4 + k][threadIdx.x] = s.opp.b[k]; }
+                s_par_mask[threadIdx.x] = m0;
+                s_par_game[threadIdx.x] = nd.game;
+                s_par_key[threadIdx.x] = nd.key | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
+            }
         }
-        const uint32_t cnt = valid ? (m0 ? (uint32_t)__popc(m0) : 1u) : 0u;
         uint32_t total;
         const uint32_t off = block_scan_256<NW>(cnt, &total, s_wave);
+        s_par_off[threadIdx.x] = off;
         staged_total += total;
-        const uint32_t info_turn = valid && s.pl ? 0x80000000u : 0u;
-        for (uint32_t r0 = 0; r0 < total; r0 += STAGE_CAP) {
-            const uint32_t nrow = total - r0 < (uint32_t)STAGE_CAP ? total - r0 : (uint32_t)STAGE_CAP;
-            for (int i = threadIdx.x; i < STAGE_T; i += STAGE_THREADS) s_tab[i] = STAGE_EMPTY;
-            // 1. stage this round's window [r0, r0 + nrow) of the block's successors
-            if (cnt && off < r0 + nrow && off + cnt > r0) {
-                uint32_t m = m0, j = off;
-                do {
-                    int o = -1;
-                    if (m) { o = __ffs(m) - 1; m &= m - 1; }
-                    if (j >= r0 && j < r0 + nrow) {
-                        Side a = s.own, b = s.opp;
-                        uint32_t key = nd.key | INFO_SELF;
-                        if (o >= 0) { apply_move(a, b, s.pl, o, die); key = key_child(nd.key, o); }
-                        const Side &s1 = s.pl ? b : a, &s2 = s.pl ? a : b;
-                        const uint32_t q = j - r0;
-                        s_row[0][q] = s1.b[0] | (s.pl ? TURN_BIT : 0u); s_row[1][q] = s1.b[1];
-                        s_row[2][q] = s1.b[2]; s_row[3][q] = s1.b[3];
-                        s_row[4][q] = s2.b[0]; s_row[5][q] = s2.b[1]; s_row[6][q] = s2.b[2]; s_row[7][q] = s2.b[3];
-                        s_row[8][q] = nd.game; s_row[9][q] = key | info_turn;
-                    }
-                    ++j;
-                } while (m);
-            }
+        for (uint32_t r0 = 0; r0 < total; r0 += CAP) {
+            const uint32_t nrow = total - r0 < (uint32_t)CAP ? total - r0 : (uint32_t)CAP;
+            for (int i = threadIdx.x; i < TSLOTS; i += NT) s_tab[i] = STAGE_EMPTY;
+            // successor -> parent map of this round's window
+            for (uint32_t j = (off > r0 ? off : r0); j < off + cnt && j < r0 + nrow; ++j) s_par_of[j - r0] = (uint16_t)threadIdx.x;
             __syncthreads();
-            // 2. hash insert
-            for (uint32_t i = threadIdx.x; i < nrow; i += STAGE_THREADS) {
-                uint32_t p[8];
+            // one lane per successor: rebuild, stage, hash
+            for (uint32_t q = threadIdx.x; q < nrow; q += NT) {
+                const uint32_t par = s_par_of[q];
+                uint32_t rank = r0 + q - s_par_off[par];
+                uint32_t m = s_par_mask[par];
+                const uint32_t pk = s_par_key[par];
+                const int pl = (int)(pk >> 31), die = (int)((pk >> 27) & 7u);
+                Side a{{s_par_plane[0][par], s_par_plane[1][par], s_par_plane[2][par], s_par_plane[3][par]}};
+                Side b{{s_par_plane[4][par], s_par_plane[5][par], s_par_plane[6][par], s_par_plane[7][par]}};
+                uint32_t key = pk & KEY_MASK;
+                if (m) {
+                    while (rank--) m &= m - 1;
+                    const int o = __ffs(m) - 1;
+                    apply_move(a, b, pl, o, die);
+                    key = key_child(key, o);
+                } else key |= INFO_SELF;
+                key |= pl ? 0x80000000u : 0u;
+                const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
+                const uint32_t game = s_par_game[par];
+                const uint32_t p[8] = {s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3], s2.b[0], s2.b[1], s2.b[2], s2.b[3]};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) p[k] = s_row[k][i];
-                const uint32_t game = s_row[8][i];
-                uint32_t h = hash_row(p, game) & (STAGE_T - 1);
+                for (int k = 0; k < 8; ++k) s_row[k][q] = p[k];
+                s_row[8][q] = game; s_row[9][q] = key;
+                // (LDS operations of a wave retire in order: the row is in place before the CAS publishes q)
+                uint32_t h = hash_row(p, game) & (TSLOTS - 1);
                 for (;;) {
-                    const uint32_t cur = atomicCAS(&s_tab[h], STAGE_EMPTY, i);
+                    const uint32_t cur = atomicCAS(&s_tab[h], STAGE_EMPTY, q);
                     if (cur == STAGE_EMPTY) break;
                     bool same = s_row[8][cur] == game;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) same = same && (s_row[k][cur] == p[k]);
                     if (same) {
-                        // the slot keeps the copy with the SMALLEST reference key (list order across blocks of the
-                        // previous ply is arbitrary, so staging order alone does not give key order)
-                        const uint32_t mykey = s_row[9][i] & KEY_MASK;
+                        const uint32_t mykey = key & KEY_MASK;
                         uint32_t c = cur;
                         while (mykey < (s_row[9][c] & KEY_MASK)) {
-                            const uint32_t old = atomicCAS(&s_tab[h], c, i);
+                            const uint32_t old = atomicCAS(&s_tab[h], c, q);
                             if (old == c) break;
                             c = old;
                         }
                         break;
                     }
-                    h = (h + 1) & (STAGE_T - 1);
+                    h = (h + 1) & (TSLOTS - 1);
                 }
-                s_pos[i] = (uint16_t)h;
+                s_pos[q] = (uint16_t)h;
             }
             __syncthreads();
-            // 3. representatives leave the CU.  Correctness does not depend on their order (the key carries it),
-            //    but locality does: each thread compacts a CONTIGUOUS slice so that a game's nodes stay adjacent
-            //    in the output list and meet again in one block of the next ply
-            const uint32_t slice = (nrow + STAGE_THREADS - 1) / STAGE_THREADS;
+            // representatives leave the CU, a contiguous slice per thread (order-preserving)
+            const uint32_t slice = (nrow + NT - 1) / NT;
             const uint32_t lo = threadIdx.x * slice, hi = lo + slice < nrow ? lo + slice : nrow;
-            uint32_t mineA = 0, mineB = 0;     // A: next node list / unique rows, B: stuck nodes of MODE_PLY2 -> F
+            uint32_t mineA = 0, mineB = 0;
             for (uint32_t i = lo; i < hi; ++i) {
                 if (s_tab[s_pos[i]] != i) continue;
                 if (MODE == MODE_PLY2 && (s_row[9][i] & INFO_SELF)) ++mineB; else ++mineA;
@@ -229,14 +240,14 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage_kernel(EnvView e, StagedV
                         sv.u_rows[2 * d + 1] = make_uint4(s_row[4][i], s_row[5][i], s_row[6][i], s_row[7][i]);
                         sv.u_info[d] = make_uint2(s_row[8][i], info & ~INFO_SELF);
                     } else {
-                        const Node out{s_row[8][i], info & 0x3FFFFFFFu};
+                        const Node out{s_row[8][i], info & 0x3FFFFFFFu & ~(7u << 27)};
                         if (MODE == MODE_PLY2 && (info & INFO_SELF)) sv.f[baseB + offB++] = out;
                         else if (MODE == MODE_PLY2) sv.d2[baseA + offA++] = out;
                         else sv.f[baseA + offA++] = out;
                     }
                 }
             }
-            __syncthreads();                   // s_row / s_tab / s_pos are rewritten by the next round
+            __syncthreads();
         }
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);

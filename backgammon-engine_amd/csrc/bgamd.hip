@@ -918,15 +918,20 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         const long long lim = (long long)env->n_cu * stage_blocks_per_cu(mode);
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
     };
+    auto sgrid2 = [&](long long max_items) {            // stage2_kernel<LEAF>: 77 KB of LDS -> two blocks per CU
+        long long b = (max_items + STAGE_THREADS - 1) / STAGE_THREADS;
+        const long long lim = (long long)env->n_cu * 2;
+        return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
+    };
     {
         KTimer t(env, s, 4);
         hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
-        hipLaunchKernelGGL(stage_kernel<MODE_PLY2>, sgrid(n * 15, MODE_PLY2), dim3(STAGE_THREADS), 0, s, env->v, sv);
-        hipLaunchKernelGGL(stage_kernel<MODE_PLY3>, sgrid(n * 225, MODE_PLY3), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(stage2_kernel<MODE_PLY2>, sgrid(n * 15, MODE_PLY2), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(stage2_kernel<MODE_PLY3>, sgrid(n * 225, MODE_PLY3), dim3(STAGE_THREADS), 0, s, env->v, sv);
     }
     {
         KTimer t(env, s, 5);
-        hipLaunchKernelGGL(stage_kernel<MODE_LEAF>, sgrid(n * 3375, MODE_LEAF), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(stage2_kernel<MODE_LEAF>, sgrid2(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
     }
     rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
     if (rc) return rc;

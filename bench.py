@@ -240,7 +240,7 @@ def main():
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            for name, key in (("eval", "eval_rows_%s_kernel" % a.precision), ("leaves", "stage_kernel<3>")):
+            for name, key in (("eval", "eval_rows_%s_kernel" % a.precision), ("leaves", "stage2_kernel<3>")):
                 if key in pmc:
                     roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
                     roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per launch)"
