@@ -9,11 +9,9 @@ struct NodeState {
     bool dbl;
 };
 
-__device__ __forceinline__ void node_state(const EnvView &e, const Node &nd, NodeState &s)
+// node_build: the position of a node from its game's planes + meta (already in registers)
+__device__ __forceinline__ void node_build(const Node &nd, const uint32_t (&p)[8], uint32_t meta, NodeState &s)
 {
-    uint32_t p[8];
-    load_planes(e, (long long)nd.game, p);
-    const uint32_t meta = e.meta[nd.game];
     s.pl = meta & 1;
     const int d1 = (meta >> 4) & 7, d2 = (meta >> 8) & 7;
     const int pass = key_pass(nd.key);
@@ -25,6 +23,13 @@ __device__ __forceinline__ void node_state(const EnvView &e, const Node &nd, Nod
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         if (k < s.len) apply_move(s.own, s.opp, s.pl, key_origin(nd.key, k), (k & 1) ? s.dB : s.dA);
+}
+
+__device__ __forceinline__ void node_state(const EnvView &e, const Node &nd, NodeState &s)
+{
+    uint32_t p[8];
+    load_planes(e, (long long)nd.game, p);
+    node_build(nd, p, e.meta[nd.game], s);
 }
 
 __device__ __forceinline__ void flag_overflow(const EnvView &e)
@@ -131,18 +136,28 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
+    // software pipeline over block iterations: the node of the NEXT iteration is loaded at the start of this one and
+    // its game's planes are gathered once it has arrived (after the staging rounds), so neither global round trip
+    // sits on the next iteration's critical path
+    Node nd_next{0u, 0u};
+    uint32_t pl_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}, meta_next = 0;
+    {
+        const unsigned long long n0 = (unsigned long long)blockIdx.x * NT + threadIdx.x;
+        if (n0 < n_in) { nd_next = in[n0]; load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
+    }
     for (unsigned long long blk = blockIdx.x; blk * NT < n_in; blk += gridDim.x) {
         const unsigned long long ni = blk * NT + threadIdx.x;
         const bool valid = ni < n_in;
+        const unsigned long long ni_next = (blk + gridDim.x) * NT + threadIdx.x;
         uint32_t cnt = 0;
         {
-            Node nd{0u, 0u};
+            const Node nd = nd_next;
             NodeState s;
             uint32_t m0 = 0;
             int die = 1;
+            if (valid) node_build(nd, pl_next, meta_next, s);
+            if (ni_next < n_in) nd_next = in[ni_next];          // arrives during the rounds below
             if (valid) {
-                nd = in[ni];
-                node_state(e, nd, s);
                 die = (s.len & 1) ? s.dB : s.dA;
                 if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
                 cnt = m0 ? (uint32_t)__popc(m0) : 1u;
@@ -249,6 +264,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
             }
             __syncthreads();
         }
+        if (ni_next < n_in) { load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
 }
