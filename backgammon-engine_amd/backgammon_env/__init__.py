@@ -291,8 +291,14 @@ class VecGame:
         return out
 
     # -- kernel timing (bench.py)
-    def time_kernels(self, enable=True):
-        _capi.check(self._lib.bgamd_env_time_kernels(self._h, int(enable)), "time_kernels")
+    def time_kernels(self, enable=True, groups=None):
+        """groups: iterable of group names to bracket (default: all): enumerate_ordered, eval, apply, step_random,
+        expand, leaves."""
+        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves")
+        arg = int(bool(enable))
+        if enable and groups is not None:
+            arg = sum(1 << names.index(g) for g in groups) << 8
+        _capi.check(self._lib.bgamd_env_time_kernels(self._h, arg), "time_kernels")
 
     def kernel_times(self):
         ms, n = (C.c_double * 8)(), (C.c_uint64 * 8)()

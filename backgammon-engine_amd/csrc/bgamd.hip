@@ -540,7 +540,7 @@ struct bgamd_env {
     bool has_weights[2] = {false, false};
     int n_cu = 256;
     // kernel timing
-    bool timing = false;
+    unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
     std::vector<hipEvent_t> ev;            // pairs
     std::vector<int> ev_kind;
     size_t ev_used = 0;
@@ -566,7 +566,7 @@ int flush_events(bgamd_env *env)
 
 struct KTimer {
     bgamd_env *env; hipStream_t s; size_t slot; bool on;
-    KTimer(bgamd_env *e, hipStream_t st, int kind) : env(e), s(st), slot(0), on(e->timing)
+    KTimer(bgamd_env *e, hipStream_t st, int kind) : env(e), s(st), slot(0), on((e->timing >> kind) & 1u)
     {
         if (!on) return;
         if (env->ev_used * 2 + 2 > env->ev.size()) {
@@ -1060,7 +1060,7 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
 {
     if (!env) return BGAMD_E_INVALID;
     if (!enable && env->timing) flush_events(env);
-    env->timing = enable != 0;
+    env->timing = enable == 1 ? 0xFFu : (unsigned)enable >> 8;      // 1 = every group, (mask << 8) = chosen groups
     return BGAMD_OK;
 }
 
