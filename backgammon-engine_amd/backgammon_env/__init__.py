@@ -121,8 +121,14 @@ class VecGame:
         return t
 
     # -- state
-    def reset(self):
-        _capi.check(self._lib.bgamd_env_reset(self._h, _stream()), "reset")
+    def reset(self, mask=None):
+        """mask=None: every lane back to episode 0.  mask [n]: only the lanes with mask != 0 restart (next episode)."""
+        if mask is None:
+            _capi.check(self._lib.bgamd_env_reset(self._h, _stream()), "reset")
+            return
+        m = self._dev(mask, torch.int32, (self.n,))
+        _capi.check(self._lib.bgamd_env_reset_lanes(self._h, _ptr(m), _stream()), "reset_lanes")
+        torch.cuda.current_stream().synchronize()
 
     def set_states(self, states28=None, turn=None):
         s = self._dev(states28, torch.int32, (self.n, 28)) if states28 is not None else None

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("bgamd_env_destroy", C.c_int, [_P]),
     ("bgamd_env_num_games", C.c_int64, [_P]),
     ("bgamd_env_reset", C.c_int, [_P, _P]),
+    ("bgamd_env_reset_lanes", C.c_int, [_P, _P, _P]),
     ("bgamd_env_set_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_flags", C.c_int, [_P, _P, _P]),

@@ -247,18 +247,22 @@ __global__ __launch_bounds__(64) void emit_kernel(EnvView e, int flags, int with
 }
 
 // ---- small state kernels ---------------------------------------------------------------------------
-__global__ void reset_kernel(EnvView e)
+// mask == nullptr: every lane restarts at episode 0.  Otherwise only the lanes with mask != 0 restart, as the NEXT
+// episode of that lane (what the auto-reset of a finished game does)
+__global__ void reset_kernel(EnvView e, const int32_t *__restrict__ mask)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n) return;
+    if (mask && mask[g] == 0) return;
     constexpr StartPlanes sp = start_planes();
     uint32_t p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = sp.p[k];
     store_planes(e, g, p);
-    const unsigned long long gid = e.lane_offset + (unsigned long long)g;
+    const uint32_t epi = mask ? e.episode[g] + 1u : 0u;
+    const unsigned long long gid = e.lane_offset + (unsigned long long)g + (unsigned long long)epi * e.lane_stride;
     e.meta[g] = meta_pack(opening_turn(e.seed, gid), 1, 1, false);
-    e.ply[g] = 0; e.episode[g] = 0; e.flags[g] = 0;
+    e.ply[g] = 0; e.episode[g] = epi; e.flags[g] = 0;
     e.cand_off[g] = 0; e.cand_cnt[g] = 0; e.chosen[g] = -1; e.chosen_seq[g] = 0; e.chosen_val[g] = 0.0f;
 }
 
@@ -720,8 +724,16 @@ int bgamd_env_reset(bgamd_env *env, void *stream)
     if (!env) return BGAMD_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(env->device));
-    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v);
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, (const int32_t *)nullptr);
     HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, s));
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask, void *stream)
+{
+    if (!env || !d_mask) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_mask);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }

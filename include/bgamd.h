@@ -78,6 +78,9 @@ int64_t bgamd_env_num_games(const bgamd_env *env);
 /* All lanes: episode 0, ply 0, start position (Game::populateBoard game.cpp:240-252), turn from
  * the opening roll protocol of play_game (train.py:89-97) on the OPENING stream. */
 int bgamd_env_reset(bgamd_env *env, void *stream);
+/* Only the lanes with d_mask[g] != 0 restart, as the next episode of that lane (start position, opening roll of
+ * the next global game id) -- what BGAMD_AUTO_RESET does for a finished game, on demand. */
+int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask /*[n]*/, void *stream);
 
 /* ---- state access (getGameBoard/getJailedCount/getBornOffCount/getTurn/setGameBoard/
  *      setBorneOffPieces/setTurn, bindings.cpp:64-85) ------------------------------------- */

@@ -639,3 +639,22 @@ def test_bench_contract_line():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+
+
+def test_reset_lanes_by_mask(bg, O):
+    """reset(mask): masked lanes restart as their next episode (start board, opening-roll turn of the next global
+    game id), the others are untouched."""
+    n = 512
+    env = bg.VecGame(n, seed=55)
+    for _ in range(20):
+        env.step_random(auto_reset=False)
+    st, tn = _np(env.states()), _np(env.turns())
+    mask = (np.arange(n) % 3 == 0).astype(np.int32)
+    env.reset(mask)
+    st2, tn2 = _np(env.states()), _np(env.turns())
+    ply, epi = [_np(x) for x in env.progress()]
+    keep = mask == 0
+    assert (st2[keep] == st[keep]).all() and (tn2[keep] == tn[keep]).all() and (epi[keep] == 0).all()
+    assert (st2[~keep] == np.array(START + [0, 0, 0, 0])).all() and (epi[~keep] == 1).all() and (ply[~keep] == 0).all()
+    for lane in np.where(~keep)[0][:40]:
+        assert tn2[lane] == O.lib().bgo_opening_turn(55, int(lane) + n)

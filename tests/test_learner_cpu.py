@@ -38,3 +38,19 @@ def test_batched_equals_sum_of_single_games_first_step(weights):
         L1.replay(torch.from_numpy(X[:1, k:k + 1]), [5], [[1, 0, 1][k]])
         acc += (L1.theta.numpy().astype(np.float64) - weights)
     assert np.abs((Lb.theta.numpy() - weights) - acc).max() < 1e-6
+
+
+def test_checkpoint_interop_state_dict_roundtrip(tmp_path, weights):
+    """the learner writes the reference's 4-tensor state_dict (train.py:513-515) and the mirror
+    policy class reads it back bit for bit (no GPU needed for the file format)."""
+    from backgammon_env.learner import TDLambdaLearner
+    from backgammon_env.policy import TDLGammonModel, flatten_state_dict
+    L = TDLambdaLearner(weights)
+    path = tmp_path / "ckpt.pth"
+    torch.save(L.state_dict(), path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {"fc1.weight": (128, 198), "fc1.bias": (128,),
+                                                          "fc2.weight": (1, 128), "fc2.bias": (1,)}
+    m = TDLGammonModel()
+    m.load_state_dict(sd)
+    assert np.array_equal(m._w, weights) and np.array_equal(flatten_state_dict(m.state_dict()), weights)
