@@ -24,7 +24,7 @@ def global_game_id(rank: int, world: int, games_per_rank: int, lane: int, episod
 def aggregate(counters: dict, elapsed_s: float, device=None):
     """Sum the integer counters over ranks and take the MAX of the elapsed time (bench contract).
     Works on any initialised process group (nccl on GPUs, gloo on CPU); identity when not distributed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dict(counters), float(elapsed_s)
     keys = sorted(counters)
     dev = device if device is not None else torch.device("cpu")

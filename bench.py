@@ -125,7 +125,8 @@ def main():
     dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # the env switch rehearses the RCCL path on one rank
+    if use_dist:
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -135,7 +136,7 @@ def main():
         if rank == 0:
             import __graft_entry__
             __graft_entry__.build()
-        if world > 1:
+        if use_dist:
             dist.barrier()
     import backgammon_env as bg
     from backgammon_env.shard import aggregate, shard_for_rank
@@ -155,14 +156,14 @@ def main():
         env.time_kernels(True, groups=("eval",))     # the dominant kernel, bracketed live in the timed region
         env.kernel_times()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         env.step_greedy(precision=prec)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
@@ -185,7 +186,7 @@ def main():
     tot, t_max = aggregate({k: st[k] for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated", "ksteps_executed")},
                            elapsed, device=dev if a.dist_backend == "nccl" else None)
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -268,7 +269,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
