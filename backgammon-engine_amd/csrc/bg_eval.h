@@ -170,11 +170,13 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
         // bandwidth is cheap; a skipped step only wastes its 1 KB read)
         const float4 *wp = sW + lane;
         float4 wa = wp[0 * 64], wb = wp[1 * 64], wc = wp[2 * 64], wd = wp[3 * 64];
+#pragma unroll 2                                   // ping-pong the prefetch registers instead of moving them
         for (int i = 0; i < 24; ++i) {
             const int nb = (4 * i + 4) * 64;
             const float4 na = wp[nb], nbb = wp[nb + 64], nc = wp[nb + 128], nd = wp[i < 23 ? nb + 192 : nb + 128];
-            // the cheap even-step operands are formed up front (in the shadow of the previous point's MFMAs);
-            // the 9-instruction odd-step decode only where that step is live (it rarely is: >= 3 checkers)
+            // the cheap even-step operands are formed up front; the 9-instruction odd-step decode only where that
+            // step is live (it rarely is: >= 3 checkers).  (Decoding the even steps inside their branches too
+            // was measured 50 % SLOWER: the MFMA group then waits on its own operand.)
             const float a0 = decode_even(rd, 0, i);
             const float a2 = decode_even(rd, 1, i);
             if ((live[0] >> i) & 1u) BG_MFMA4(a0, wa);
