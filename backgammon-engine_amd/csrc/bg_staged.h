@@ -31,7 +31,8 @@ __host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
 struct Node { uint32_t game, key; };
 
 // ---- workgroup exclusive scan (NW waves); returns the prefix, *total = sum over the block ----
-template <int NW = 4>
+// LEAD_SYNC = false: the caller guarantees a barrier since the last read of s_wave / s_slot
+template <int NW = 4, bool LEAD_SYNC = true>
 __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *s_wave /*[NW]*/)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -41,7 +42,7 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
         const uint32_t t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    __syncthreads();                       // s_wave may still be read by the previous scan
+    if (LEAD_SYNC) __syncthreads();        // s_wave may still be read by the previous scan
     if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -56,9 +57,10 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
 }
 
 // bump allocation of `total` entries for the whole block (thread 0 does the atomic)
+template <bool LEAD_SYNC = true>
 __device__ __forceinline__ unsigned long long block_alloc(unsigned long long *top, uint32_t total, unsigned long long *s_slot)
 {
-    __syncthreads();
+    if (LEAD_SYNC) __syncthreads();
     if (threadIdx.x == 0) *s_slot = total ? atomicAdd(top, (unsigned long long)total) : 0ull;
     __syncthreads();
     return *s_slot;

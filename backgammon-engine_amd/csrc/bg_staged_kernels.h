@@ -169,7 +169,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
             }
         }
         uint32_t total;
-        const uint32_t off = block_scan_256<NW>(cnt, &total, s_wave);
+        const uint32_t off = block_scan_256<NW, false>(cnt, &total, s_wave);   // barrier at the end of the last round
         s_par_off[threadIdx.x] = off;
         staged_total += total;
         for (uint32_t r0 = 0; r0 < total; r0 += CAP) {
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                 if (MODE == MODE_PLY2 && (s_row[9][i] & INFO_SELF)) ++mineB; else ++mineA;
             }
             uint32_t totA, totB = 0;
-            uint32_t offA = block_scan_256<NW>(mineA, &totA, s_wave);
+            uint32_t offA = block_scan_256<NW, false>(mineA, &totA, s_wave);     // barrier after the insert phase
             unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
             const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
-            const unsigned long long baseA = block_alloc(topA, totA, &s_slot);
+            const unsigned long long baseA = block_alloc<false>(topA, totA, &s_slot);   // the scan just synchronised
             uint32_t offB = 0;
             unsigned long long baseB = 0;
             if (MODE == MODE_PLY2) {
