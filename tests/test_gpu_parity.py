@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import random_boards as _random_boards
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -71,6 +73,40 @@ def test_enumerate_vs_oracle_4096(bg, O):
         tot += len(l)
     assert tot == cnts.sum()
     assert (_np(env.states()) == st0).all()          # enumeration does not mutate (tests.cpp:390-399)
+
+
+def test_enumerate_arbitrary_positions_vs_oracle(bg, O):
+    """8 192 arbitrary positions x random dice x random mover: full ordered enumeration, legalMoves for every die
+    and a greedy-free random step (bounded kernels) against the oracle."""
+    n = 8192
+    st = _random_boards(n, 42)
+    rng = np.random.RandomState(43)
+    pl = rng.randint(0, 2, n).astype(np.int32)
+    dice = rng.randint(1, 7, (n, 2)).astype(np.int32)
+    dice[::5, 1] = dice[::5, 0]                             # plenty of doubles
+    env = bg.VecGame(n, seed=44, arena_rows=16 << 20)
+    env.set_states(st, pl)
+    env.set_dice(dice)
+    offs, cnts, est, esq, eln = [_np(x) for x in env.enumerate()]
+    for lane in range(n):
+        s = O.State.from28(st[lane], pl[lane])
+        q, l, a = O.evaluate_turn_sequences(s, int(pl[lane]), int(dice[lane, 0]), int(dice[lane, 1]))
+        assert cnts[lane] == len(l), (lane, st[lane].tolist(), pl[lane], dice[lane])
+        o = int(offs[lane])
+        assert (est[o:o + len(l)] == a).all() and (esq[o:o + len(l)] == q).all(), lane
+    for die in (1, 3, 6):
+        cnt, pairs = env.legal_moves(pl, np.full(n, die))
+        cnt, pairs = _np(cnt), _np(pairs)
+        for lane in range(0, n, 7):
+            exp = O.legal_moves(O.State.from28(st[lane], pl[lane]), int(pl[lane]), die)
+            assert [tuple(x) for x in pairs[lane, :cnt[lane]].tolist()] == exp, lane
+    u = rng.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    env.step_random(roll=False, auto_reset=False, choice_u32=u)
+    post = _np(env.states())
+    for lane in range(0, n, 3):
+        s = O.State.from28(st[lane], pl[lane])
+        O.step(s, int(dice[lane, 0]), int(dice[lane, 1]), 0, choice_u32=int(u[lane]))
+        assert (post[lane] == s.to28()).all(), lane
 
 
 def test_start_position_counts(bg, golden_dir):

@@ -240,3 +240,42 @@ def test_g5_greedy_trajectories(golden_dir, weights):
             best = v.max() if rows[r, 30] == 0 else v.min()
             assert abs(v[k] - best) < 1e-5
     assert n_checked > 0.9 * len(rows)
+
+
+def test_oracle_vs_compiled_reference_on_arbitrary_boards():
+    """Positions that play never reaches (random placement, heavy stacks, late bear-off boards): the oracle
+    against the UNMODIFIED reference compiled into oracle/_ref -- runs wherever that module is present (the
+    binding cannot set bar counts, so those stay 0 here; bar positions are pinned by G1/G3)."""
+    import importlib.util
+    import sys
+    from helpers import random_boards
+    ref_dir = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref")
+    so = [f for f in os.listdir(ref_dir)] if os.path.isdir(ref_dir) else []
+    so = [f for f in so if f.startswith("backgammon_env") and f.endswith(".so")]
+    if not so:
+        pytest.skip("oracle/_ref not built here")
+    spec = importlib.util.spec_from_file_location("backgammon_env", os.path.join(ref_dir, so[0]))
+    saved = sys.modules.pop("backgammon_env", None)
+    try:
+        rb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rb)
+    finally:
+        if saved is not None:
+            sys.modules["backgammon_env"] = saved
+    p1, p2 = rb.Player("a", rb.PlayerType.PLAYER1), rb.Player("b", rb.PlayerType.PLAYER2)
+    st = random_boards(1500, 7, with_bar=False)
+    rng = np.random.RandomState(8)
+    for i in range(len(st)):
+        g = rb.Game(0)
+        g.setPlayers(p1, p2)
+        g.setGameBoard([int(v) for v in st[i, :24]])
+        g.setBorneOffPieces(0, int(st[i, 26])); g.setBorneOffPieces(1, int(st[i, 27]))
+        pl, d1, d2 = int(rng.randint(2)), int(rng.randint(1, 7)), int(rng.randint(1, 7))
+        if i % 5 == 0:
+            d2 = d1
+        seqs, states = g.evaluateTurnSequences(pl, d1, d2)
+        q, ln, a = O.evaluate_turn_sequences(O.State.from28(st[i], pl), pl, d1, d2)
+        assert [list(map(tuple, x)) for x in seqs] == O.sequences_as_lists(q, ln), (i, st[i].tolist(), pl, d1, d2)
+        assert states.shape == a.shape and (states == a).all()
+        for die in (1, 4, 6):
+            assert g.legalMoves(pl, die) == O.legal_moves(O.State.from28(st[i], pl), pl, die)
