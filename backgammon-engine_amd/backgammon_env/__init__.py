@@ -23,7 +23,7 @@ from . import _capi
 from ._capi import (AUTO_RESET, BF16, F16X2, F32, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
                     BgamdError)
 
-__all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed"]
+__all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed", "pack_rows"]
 
 ERR_MESSAGES = {                                   # cppsrc/game.cpp:585-642, in source order
     0: "", 1: "Invalid origin", 2: "Origin out of range", 3: "Destination out of range",
@@ -48,6 +48,18 @@ def _stream():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pack_rows(states28, turn, device="cuda"):
+    """[..., 28] reference-layout states + turn (scalar or [...]) -> int32 [..., 8] 32-byte rows (the trajectory
+    log's format: 8 bit planes, turn of the side to move in plane 0 bit 31)."""
+    st = torch.as_tensor(states28, dtype=torch.int32).to(device).contiguous()
+    lead = st.shape[:-1]
+    n = st.numel() // 28
+    t = torch.as_tensor(turn, dtype=torch.int32).to(device).expand(lead).contiguous()
+    out = torch.empty((n, 8), dtype=torch.int32, device=st.device)
+    _capi.check(_capi.load().bgamd_pack_rows(_ptr(st), _ptr(t), n, _ptr(out), _stream()), "pack_rows")
+    return out.reshape(*lead, 8)
 
 
 class PlayerType(enum.IntEnum):                    # bindings.cpp:46-48 (unscoped enum: equals ints)

@@ -99,9 +99,113 @@ class TDLambdaLearner:
         return float(sq.item()), int(cnt.item())
 
     def state_dict(self):
-        W1, b1, W2, b2 = self._split(self.theta.detach().cpu())
+        W1, b1, W2, b2 = TDLambdaLearner._split(self.theta.detach().cpu())
         return {"fc1.weight": W1.clone(), "fc1.bias": b1.clone(), "fc2.weight": W2.reshape(1, 128).clone(),
                 "fc2.bias": b2.clone()}
+
+
+class DeviceTDLambdaLearner:
+    """The same lock-step TD(λ) replay as TDLambdaLearner.replay, in hand-written HIP kernels (csrc/bg_learner.h,
+    C ABI bgamd_td_*): it reads the env's 32-byte trajectory rows directly (no [T, G, 198] tensor), keeps the
+    per-game traces in HBM and touches them once per step (read + write, the Σ_g fp32(αδ_g)·e_g reduction fused in
+    the same pass).  No CPU fallback: needs the HIP library and a device."""
+
+    def __init__(self, weights_flat, max_games: int, device=None, alpha: float = 0.1, lam: float = 0.7):
+        import ctypes as C
+        from . import _capi
+        self._C, self._capi, self._lib = C, _capi, _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.BgamdError("DeviceTDLambdaLearner needs a gfx950 device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.max_games = int(max_games)
+        h = C.c_void_p()
+        _capi.check(self._lib.bgamd_td_create(C.byref(h), self.max_games, self.device.index or 0), "td_create")
+        self._h = h
+        self.learning_rate, self.lambda_decay = float(alpha), float(lam)
+        self._keep = None
+        self.set_weights(weights_flat)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bgamd_td_destroy(h)
+
+    def _p(self, t):
+        return self._C.c_void_p(t.data_ptr())
+
+    def _s(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_weights(self, weights_flat):
+        w = torch.as_tensor(weights_flat, dtype=torch.float32).flatten().to(self.device).contiguous()
+        if w.numel() != 25601:
+            raise ValueError("expected 25601 weights")
+        self._capi.check(self._lib.bgamd_td_set_weights(self._h, self._p(w), self._s()), "td_set_weights")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    @property
+    def theta(self):
+        out = torch.empty(25601, dtype=torch.float32, device=self.device)
+        self._capi.check(self._lib.bgamd_td_get_weights(self._h, self._p(out), self._s()), "td_get_weights")
+        return out
+
+    update_learning_params = TDLambdaLearner.update_learning_params
+
+    def state_dict(self):
+        return TDLambdaLearner.state_dict(self)
+
+    def time_trace_kernel(self, enable=True):
+        self._capi.check(self._lib.bgamd_td_time(self._h, 1 if enable else 0), "td_time")
+
+    def trace_kernel_times(self):
+        C = self._C
+        ms, n, gs = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._capi.check(self._lib.bgamd_td_times(self._h, C.byref(ms), C.byref(n), C.byref(gs)), "td_times")
+        return ms.value, n.value, gs.value
+
+    def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0):
+        """rows: int32 [T, n, 8] trajectory log (VecGame.record_trajectory / play_round), lengths: int [n] logged
+        turns per lane (0 = do not replay), p1_won: bool [n].  Returns (Σ δ², number of (game, step) updates)."""
+        C, lib, chk = self._C, self._lib, self._capi.check
+        rows = rows.contiguous()
+        T, n = int(rows.shape[0]), int(rows.shape[1])
+        lengths = torch.as_tensor(lengths, device=self.device).to(torch.int32).contiguous()
+        won = torch.as_tensor(p1_won, device=self.device).to(torch.uint8).contiguous()
+        if int(lengths.max().item()) > T:
+            raise ValueError("a game is longer than the trajectory log")
+        sl, order = torch.sort(lengths, descending=True, stable=True)
+        order = order.to(torch.int32).contiguous()
+        n_games = int((sl > 0).sum().item())
+        if n_games > self.max_games:
+            raise ValueError(f"{n_games} games > max_games={self.max_games}")
+        n_steps = int(sl[0].item()) if n_games else 0
+        # running games per step: a prefix of the order
+        hist = torch.bincount(sl[:n_games].long(), minlength=n_steps + 1)
+        n_active = (n_games - torch.cumsum(hist, 0)[:n_steps]).cpu().tolist()      # games with length > t
+        self._keep = (rows, lengths, won, order)
+        chk(lib.bgamd_td_begin(self._h, self._p(rows), T, n, self._p(order), n_games, self._p(lengths), self._p(won),
+                               self._s()), "td_begin")
+        alpha = float(self.learning_rate) * float(batch_scale)
+        lam = float(self.lambda_decay)
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if not distributed:
+            arr = (C.c_int64 * max(n_steps, 1))(*n_active)
+            chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
+        else:
+            ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)      # every rank issues the same collectives
+            upd = torch.zeros(25601, dtype=torch.float32, device=self.device)
+            for t in range(int(ns.item())):
+                if t < n_steps:
+                    chk(lib.bgamd_td_step(self._h, t, n_active[t], alpha, lam, self._p(upd), self._s()), "td_step")
+                else:
+                    upd.zero_()
+                dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)  # the ONE collective per training step
+                chk(lib.bgamd_td_apply(self._h, self._p(upd), self._s()), "td_apply")
+        sq, cnt = C.c_double(), C.c_int64()
+        chk(lib.bgamd_td_stats(self._h, C.byref(sq), C.byref(cnt)), "td_stats")
+        self._keep = None
+        return float(sq.value), int(cnt.value)
 
 
 def play_round(env, max_plies: int = 512, epsilon: float = 0.0, precision=0):

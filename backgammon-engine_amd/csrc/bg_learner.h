@@ -1,0 +1,310 @@
+// bg_learner.h -- TD(lambda) learner kernels: the reference's apply_td_updates
+// (pysrc/TD(λ) model/train.py:124-172) with the eligibility traces of model.py:48-53, as a lock-step replay
+// over the turn index of many games.  Per step t, for every game still running (the games are ordered by
+// decreasing length, so the running ones are a prefix of the order):
+//
+//   td_forward_kernel  8 games per workgroup, thread per hidden unit: decode x_t and x_{t+1} from the 32-byte
+//                      trajectory rows, h = σ(W1 x + b1), v = σ(W2 h + b2) for both, δ (train.py:136-141, terminal
+//                      step train.py:165-166), g = v(1-v), the factors of the closed-form gradient
+//                        ∇W1 = db1 ⊗ x, ∇b1 = db1 = g W2 ⊙ h ⊙ (1-h), ∇W2 = g h, ∇b2 = g
+//                      written as one 464-float "factor row" per game, coef = fp32(α δ) with α δ formed in
+//                      float64 first (train.py:147,160,169)
+//   td_trace_kernel    the HBM-bound pass: e ← λ e + ∇ (model.py:52-53 semantics, train.py:150-158), one read and
+//                      one write of the 25 601-float trace of every running game, and in the same pass the
+//                      block's share of Σ_g coef_g · e_g (train.py:159-161) -> partial sums per game group
+//   td_reduce_kernel   Σ over game groups -> the 25 601-float update; θ += update (or hand it to the caller for
+//                      the one all-reduce of the step), W1 re-transposed for the next forward
+//
+// Algorithmic bytes per (game, step): 2 · 25 601 · 4 = 204 808 B of trace traffic (SURVEY §8d "learner").
+#pragma once
+#include "bg_board.h"
+#include "bg_eval.h"
+
+namespace bg {
+
+constexpr int TD_P = 25601;              // W1[128][198] | b1[128] | W2[128] | b2
+constexpr int TD_LD = 25664;             // trace row stride in floats (multiple of 64)
+constexpr int TD_OFF_B1 = 25344, TD_OFF_W2 = 25472, TD_OFF_B2 = 25600;
+// factor row of one game: x[198] | 1 | 0 | db1[128] | g·h[128] | g | pad
+constexpr int TD_F_ONE = 198, TD_F_ZERO = 199, TD_F_DB1 = 200, TD_F_GH = 328, TD_F_G = 456, TD_FLD = 464;
+constexpr int TD_GB = 8;                 // games per forward workgroup
+constexpr int TD_TRACE_THREADS = 256;
+constexpr int TD_SLICES = (TD_LD / 4 + TD_TRACE_THREADS - 1) / TD_TRACE_THREADS;   // 26
+constexpr int TD_CHUNK = 8;              // games staged in LDS at a time by the trace kernel
+constexpr int TD_MAX_GROUPS = 256;
+
+struct TdView {
+    float *theta;                        // [TD_LD] flat parameters
+    float *w1t;                          // [198][128] transposed fc1.weight for the forward kernel
+    float *e;                            // [max_games][TD_LD] traces, indexed by order position
+    float *fac;                          // [max_games][TD_FLD]
+    float *coef;                         // [max_games]
+    double *sq;                          // [max_games] Σ δ² per game
+    float *partial;                      // [TD_MAX_GROUPS][TD_LD]
+    const uint4 *rows;                   // [T][n_lanes] x 2 uint4
+    const int32_t *order;                // [n_games] lane index, by decreasing length
+    const int32_t *length;               // [n_lanes]
+    const uint8_t *p1_won;               // [n_lanes]
+    long long T, n_lanes, n_games;
+};
+
+__device__ __forceinline__ float td_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
+typedef float td_f32x4 __attribute__((ext_vector_type(4)));
+
+// 8 games x {s_t, s_{t+1}} per workgroup of 128 threads
+__global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
+{
+    constexpr int NR = 2 * TD_GB;                         // 16 rows: [s][game]
+    __shared__ __attribute__((aligned(16))) float xs[N_IN][NR];
+    __shared__ float hs[NR][N_HID + 1];
+    __shared__ float outs[NR];
+    __shared__ float gs[TD_GB];
+    const int tid = threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * TD_GB;
+
+    // ---- decode: thread = (row r, chunk c of 3 board points) ----
+    {
+        const int r = tid & (NR - 1), c = tid >> 4;       // 8 chunks
+        const int s = r / TD_GB, g = r % TD_GB;
+        const long long i = i0 + g;
+        bool live = i < n_active;
+        int lane = 0, len = 0;
+        if (live) {
+            lane = v.order[i];
+            len = v.length[lane];
+            live = (t + s) < len && (t + s) < v.T;        // s_{t+1} does not exist on the terminal step
+        }
+        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            const uint4 *src = v.rows + ((t + s) * v.n_lanes + lane) * 2;
+            const uint4 u0 = src[0], u1 = src[1];
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+        const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int pt = 3 * c + k;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cn = count_at(sd[q], pt + 1);
+                xs[8 * pt + 4 * q + 0][r] = cn >= 1 ? 1.0f : 0.0f;
+                xs[8 * pt + 4 * q + 1][r] = cn >= 2 ? 1.0f : 0.0f;
+                xs[8 * pt + 4 * q + 2][r] = cn >= 3 ? 1.0f : 0.0f;
+                xs[8 * pt + 4 * q + 3][r] = cn >= 4 ? 0.5f * (float)(cn - 3) : 0.0f;
+            }
+        }
+        if (c == 0) {
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            xs[192][r] = live ? (turn == 0 ? 1.0f : 0.0f) : 0.0f;
+            xs[193][r] = live ? (turn == 0 ? 0.0f : 1.0f) : 0.0f;
+            xs[194][r] = 0.5f * (float)count_at(sd[0], 0);
+            xs[195][r] = 0.5f * (float)count_at(sd[1], 25);
+            xs[196][r] = (float)count_at(sd[0], 25) / 15.0f;
+            xs[197][r] = (float)count_at(sd[1], 0) / 15.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- hidden layer: thread n owns unit n for all 16 rows ----
+    const int n = tid;
+    float acc[NR];
+    {
+        const float b = v.theta[TD_OFF_B1 + n];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = b;
+    }
+    // fc1.weight streams from L2 in batches of 18 columns, the next batch in flight while this one is used
+    constexpr int WB = 18;                                 // 198 = 11 x 18
+    float wa[WB], wb[WB];
+#pragma unroll
+    for (int k = 0; k < WB; ++k) wa[k] = v.w1t[k * N_HID + n];
+#pragma unroll 1
+    for (int j0 = 0; j0 < N_IN; j0 += 2 * WB) {
+        const bool more = j0 + WB < N_IN;
+#pragma unroll
+        for (int k = 0; k < WB; ++k) wb[k] = more ? v.w1t[(j0 + WB + k) * N_HID + n] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const float4 *xr = reinterpret_cast<const float4 *>(&xs[j0 + k][0]);
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+                const float4 x4 = xr[q];
+                acc[4 * q + 0] = fmaf(wa[k], x4.x, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(wa[k], x4.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(wa[k], x4.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(wa[k], x4.w, acc[4 * q + 3]);
+            }
+        }
+        if (!more) break;
+        const bool more2 = j0 + 2 * WB < N_IN;
+#pragma unroll
+        for (int k = 0; k < WB; ++k) wa[k] = more2 ? v.w1t[(j0 + 2 * WB + k) * N_HID + n] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const float4 *xr = reinterpret_cast<const float4 *>(&xs[j0 + WB + k][0]);
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+                const float4 x4 = xr[q];
+                acc[4 * q + 0] = fmaf(wb[k], x4.x, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(wb[k], x4.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(wb[k], x4.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(wb[k], x4.w, acc[4 * q + 3]);
+            }
+        }
+    }
+    const float w2 = v.theta[TD_OFF_W2 + n];
+    float h[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        h[r] = td_sigmoid(acc[r]);
+        hs[r][n] = w2 * h[r];
+    }
+    __syncthreads();
+    // ---- output unit: thread = (row r, eighth e) sums 16 products, 8-lane butterfly ----
+    {
+        const int r = tid >> 3, e8 = tid & 7;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += hs[r][e8 * 16 + k];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (e8 == 0) outs[r] = td_sigmoid(s + v.theta[TD_OFF_B2]);
+    }
+    __syncthreads();
+    // ---- δ, g, coef per game ----
+    if (tid < TD_GB) {
+        const long long i = i0 + tid;
+        float g = 0.0f;
+        if (i < n_active) {
+            const int lane = v.order[i];
+            const int len = v.length[lane];
+            const float val = outs[tid], vnext = outs[TD_GB + tid];
+            const float z = v.p1_won[lane] ? 1.0f : 0.0f;
+            const float delta = (t + 1 >= len) ? z - val : vnext - val;   // lengths never exceed the log (host check)
+            g = val * (1.0f - val);
+            v.coef[i] = (float)(alpha * (double)delta);
+            v.sq[i] += (double)delta * (double)delta;
+        }
+        gs[tid] = g;
+    }
+    __syncthreads();
+    // ---- factor rows ----
+#pragma unroll
+    for (int gq = 0; gq < TD_GB; ++gq) {
+        const long long i = i0 + gq;
+        if (i >= n_active) break;
+        float *f = v.fac + i * TD_FLD;
+        const float g = gs[gq], hh = h[gq];
+        f[TD_F_DB1 + n] = (g * w2) * (1.0f - hh) * hh;
+        f[TD_F_GH + n] = g * hh;
+        f[n] = xs[n][gq];
+        if (n + 128 < N_IN) f[n + 128] = xs[n + 128][gq];
+        if (n == 0) { f[TD_F_ONE] = 1.0f; f[TD_F_ZERO] = 0.0f; f[TD_F_G] = g; }
+    }
+}
+
+// grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace; `ng` games per group
+template <bool FIRST>
+__global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, long long n_active, int ng, float lambda)
+{
+    __shared__ float fs[TD_CHUNK][TD_FLD];
+    __shared__ float cs[TD_CHUNK];
+    const int tid = threadIdx.x;
+    const int p0 = (blockIdx.x * TD_TRACE_THREADS + tid) * 4;
+    const bool in_row = p0 < TD_LD;
+    const long long g0 = (long long)blockIdx.y * ng;
+    int ia[4], ib[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        if (p < TD_OFF_B1) { const int n = p / N_IN; ia[k] = TD_F_DB1 + n; ib[k] = p - n * N_IN; }
+        else if (p < TD_OFF_W2) { ia[k] = TD_F_DB1 + (p - TD_OFF_B1); ib[k] = TD_F_ONE; }
+        else if (p < TD_OFF_B2) { ia[k] = TD_F_GH + (p - TD_OFF_W2); ib[k] = TD_F_ONE; }
+        else if (p == TD_OFF_B2) { ia[k] = TD_F_G; ib[k] = TD_F_ONE; }
+        else { ia[k] = TD_F_ZERO; ib[k] = TD_F_ZERO; }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < ng; c += TD_CHUNK) {
+        const long long gb = g0 + c;
+        if (gb >= n_active) break;
+        long long left = n_active - gb;
+        if (left > ng - c) left = ng - c;
+        const int m = left < TD_CHUNK ? (int)left : TD_CHUNK;
+        __syncthreads();
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
+            float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
+            for (int q = tid; q < m * (TD_FLD / 4); q += TD_TRACE_THREADS) dst[q] = src[q];
+            if (tid < m) cs[tid] = v.coef[gb + tid];
+        }
+        // the trace loads of the whole chunk go out before the first use
+        td_f32x4 ev[TD_CHUNK];
+        if (!FIRST && in_row) {
+#pragma unroll
+            for (int q = 0; q < TD_CHUNK; ++q)
+                if (q < m) {
+                    const td_f32x4 *ep = reinterpret_cast<const td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
+                    ev[q] = __builtin_nontemporal_load(ep);
+                }
+        }
+        __syncthreads();
+        if (in_row) {
+#pragma unroll
+            for (int q = 0; q < TD_CHUNK; ++q) {
+                if (q < m) {
+                    td_f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (!FIRST) x = ev[q];
+                    x.x = fmaf(lambda, x.x, fs[q][ia[0]] * fs[q][ib[0]]);
+                    x.y = fmaf(lambda, x.y, fs[q][ia[1]] * fs[q][ib[1]]);
+                    x.z = fmaf(lambda, x.z, fs[q][ia[2]] * fs[q][ib[2]]);
+                    x.w = fmaf(lambda, x.w, fs[q][ia[3]] * fs[q][ib[3]]);
+                    td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
+                    __builtin_nontemporal_store(x, ep);
+                    const float cf = cs[q];
+                    acc.x = fmaf(cf, x.x, acc.x);
+                    acc.y = fmaf(cf, x.y, acc.y);
+                    acc.z = fmaf(cf, x.z, acc.z);
+                    acc.w = fmaf(cf, x.w, acc.w);
+                }
+            }
+        }
+    }
+    if (in_row) *reinterpret_cast<float4 *>(v.partial + (long long)blockIdx.y * TD_LD + p0) = acc;
+}
+
+// block 256 = 64 parameters x 4 group lanes.  upd (optional) receives the summed update; apply adds it to theta
+__global__ __launch_bounds__(256) void td_reduce_kernel(TdView v, int n_groups, float *upd, int apply)
+{
+    __shared__ float red[4][64];
+    const int pi = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + pi;
+    float s = 0.0f;
+    if (p < TD_P) {
+#pragma unroll 8
+        for (int g = gl; g < n_groups; g += 4) s += v.partial[(long long)g * TD_LD + p];
+    }
+    red[gl][pi] = s;
+    __syncthreads();
+    if (gl == 0 && p < TD_P) {
+        const float u = (red[0][pi] + red[1][pi]) + (red[2][pi] + red[3][pi]);
+        if (upd) upd[p] = u;
+        if (apply) {
+            const float th = v.theta[p] + u;
+            v.theta[p] = th;
+            if (p < TD_OFF_B1) { const int n = p / N_IN, j = p - n * N_IN; v.w1t[j * N_HID + n] = th; }
+        }
+    }
+}
+
+// theta += upd (after the caller's all-reduce), or theta = upd (set); refreshes the transposed fc1.weight
+__global__ void td_apply_kernel(TdView v, const float *upd, int set)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= TD_P) return;
+    const float th = set ? upd[p] : v.theta[p] + upd[p];
+    v.theta[p] = th;
+    if (p < TD_OFF_B1) { const int n = p / N_IN, j = p - n * N_IN; v.w1t[j * N_HID + n] = th; }
+}
+
+}  // namespace bg

@@ -20,7 +20,15 @@ struct RandomView {
     unsigned long long *top;   // bump pointer
 };
 
-__global__ __launch_bounds__(256) void rnd_tasks_kernel(EnvView e, RandomView rv, int flags)
+// ε-greedy (model.py:205-206): the lanes whose TURN-stream draw falls below epsilon pick uniformly
+__device__ __forceinline__ bool explore_draw(const LaneCtx &c, float epsilon)
+{
+    return epsilon > 0.0f && (float)(c.x.w >> 8) * (1.0f / 16777216.0f) < epsilon;
+}
+
+// explore_eps < 0: every live lane gets tasks (the random-policy step); otherwise only the exploring lanes of an
+// ε-greedy step do (dice already stored, flags without BGAMD_ROLL)
+__global__ __launch_bounds__(256) void rnd_tasks_kernel(EnvView e, RandomView rv, int flags, float explore_eps)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_slot;
@@ -31,7 +39,8 @@ __global__ __launch_bounds__(256) void rnd_tasks_kernel(EnvView e, RandomView rv
     split_sides(c.p, c.turn, own, opp);
     const bool dbl = c.d1 == c.d2;
     uint32_t ma = 0, mb = 0, nT = 0;
-    if (c.live) {
+    const bool want = c.live && (explore_eps < 0.0f || explore_draw(c, explore_eps));
+    if (want) {
         ma = legal_origins(own, opp, c.turn, c.d1);
         if (!dbl) { mb = legal_origins(own, opp, c.turn, c.d2); nT = (uint32_t)(__popc(ma) + __popc(mb)); }
         else if (ma == 0) nT = 1;                                   // ONE empty sequence
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void rnd_tasks_kernel(EnvView e, RandomView rv
     const unsigned long long base = block_alloc(rv.top, tot, &s_slot);
     const bool ok = base + tot <= (unsigned long long)rv.cap;
     if (!ok) flag_overflow(e);
-    if (c.live) {
+    if (want) {
         const uint32_t gg = (uint32_t)g;
         Node *out = rv.tasks + base;
         if (ok) {
@@ -76,8 +85,8 @@ __global__ __launch_bounds__(256) void rnd_tasks_kernel(EnvView e, RandomView rv
         }
         rv.task_off[g] = (uint32_t)(base + off - nT);
         rv.task_n[g] = ok ? nT : 0u;
-        if (flags & BGAMD_ROLL) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
     } else if (g < e.n) rv.task_n[g] = 0u;
+    if (c.live && (flags & BGAMD_ROLL)) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
 }
 
 // sequences below a task, and (SELECT) the position + packed origins of the `want`-th one
@@ -129,6 +138,39 @@ __global__ __launch_bounds__(256) void rnd_count_kernel(EnvView e, RandomView rv
     }
 }
 
+// the k-th sequence (reference order) of game g out of its counted tasks: afterstate into (ro, rp), key into rk
+__device__ __forceinline__ void task_select(const EnvView &e, const RandomView &rv, uint32_t t0, uint32_t nT, uint32_t k,
+                                            Side &ro, Side &rp, uint32_t &rk)
+{
+    uint32_t acc = 0, t = 0;
+    for (; t + 1 < nT; ++t) {
+        const uint32_t cnt = rv.task_count[t0 + t];
+        if (k < acc + cnt) break;
+        acc += cnt;
+    }
+    const Node nd = rv.tasks[t0 + t];
+    NodeState s;
+    node_state(e, nd, s);
+    ro = s.own; rp = s.opp; rk = nd.key;
+    task_walk<true>(s, nd.key, k - acc, ro, rp, rk);
+}
+
+__device__ __forceinline__ bool explore_pick(const EnvView &e, const ExploreView &xv, long long g, uint32_t u, Side &own,
+                                             Side &opp, uint32_t &key, uint32_t &k, uint32_t &C)
+{
+    const uint32_t nT = xv.task_n[g];
+    if (nT == 0) return false;                             // arena overflow (flagged): the lane stays greedy
+    const uint32_t t0 = xv.task_off[g];
+    C = 0;
+    for (uint32_t t = 0; t < nT; ++t) C += xv.task_count[t0 + t];
+    if (C == 0) return false;
+    k = (uint32_t)(((unsigned long long)u * C) >> 32);
+    RandomView rv{};
+    rv.tasks = const_cast<Node *>(xv.tasks); rv.task_count = const_cast<uint32_t *>(xv.task_count);
+    task_select(e, rv, t0, nT, k, own, opp, key);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void rnd_select_kernel(EnvView e, RandomView rv, int flags, const uint32_t *__restrict__ choice)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -143,18 +185,9 @@ __global__ __launch_bounds__(256) void rnd_select_kernel(EnvView e, RandomView r
     if (C > 0) {
         const uint32_t u = choice ? choice[g] : c.x.z;
         const uint32_t k = (uint32_t)(((unsigned long long)u * C) >> 32);
-        uint32_t acc = 0, t = 0;
-        for (; t < nT; ++t) {
-            const uint32_t cnt = rv.task_count[t0 + t];
-            if (k < acc + cnt) break;
-            acc += cnt;
-        }
-        const Node nd = rv.tasks[t0 + t];
-        NodeState s;
-        node_state(e, nd, s);
-        Side ro = s.own, rp = s.opp;
-        uint32_t rk = nd.key;
-        task_walk<true>(s, nd.key, k - acc, ro, rp, rk);
+        Side ro, rp;
+        uint32_t rk;
+        task_select(e, rv, t0, nT, k, ro, rp, rk);
         join_sides(ro, rp, c.turn, c.p);
         const int len = key_len(rk), pass = key_pass(rk);
         uint32_t origins = 0;

@@ -281,7 +281,13 @@ struct IndexVisitor {
 };
 
 // ---- apply: lane per game ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, int flags, float epsilon)
+struct ExploreView {                                       // counted tasks of the exploring lanes (bg_random_kernels.h)
+    const Node *tasks; const uint32_t *task_count, *task_off, *task_n;
+};
+__device__ __forceinline__ bool explore_pick(const EnvView &e, const ExploreView &xv, long long g, uint32_t u, Side &own,
+                                             Side &opp, uint32_t &key, uint32_t &k, uint32_t &C);
+
+__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     LaneCtx c;
@@ -294,34 +300,33 @@ __global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, in
     if (has) {
         Side own, opp;
         split_sides(c.p, c.turn, own, opp);
+        // model.py:205-206: an exploring lane takes the k-th sequence of the reference-order list, k from the TURN
+        // stream, located through the lane's counted tasks (bounded work; no lane walks a whole tree)
         const bool explore = epsilon > 0.0f && (float)(c.x.w >> 8) * (1.0f / 16777216.0f) < epsilon;
         uint32_t key = ~(uint32_t)pack & 0x7FFFFFFFu;
         const uint32_t vb = (uint32_t)(pack >> 32);
         cval = __uint_as_float(c.turn ? ~vb : vb);
-        if (explore) {                                     // model.py:205-206, index from the TURN stream
-            CountVisitor cv;
-            walk_sequences(own, opp, c.turn, c.d1, c.d2, cv);
-            const uint32_t k = (uint32_t)(((unsigned long long)c.x.z * cv.n) >> 32);
-            SelectVisitor sel(k);
-            walk_sequences(own, opp, c.turn, c.d1, c.d2, sel);
-            own = sel.own; opp = sel.opp;
-            cseq = sel.seq | (c.turn ? (1u << 29) : 0u); chosen = (int32_t)k; ccount = cv.n; cval = 0.0f;
-        } else {
+        uint32_t xk = 0, xC = 0;
+        const bool explored = explore && explore_pick(e, xv, g, c.x.z, own, opp, key, xk, xC);
+        {
             const int len = key_len(key), pass = key_pass(key);
             const int dA = pass ? c.d2 : c.d1, dB = pass ? c.d1 : c.d2;
             uint32_t origins = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < len) origins |= (uint32_t)key_origin(key, k) << (5 * k);
-            if (flags & BGAMD_WANT_INDEX) {                // reference-order index + list length (slow path)
+            if (explored) { chosen = (int32_t)xk; ccount = xC; cval = 0.0f; }
+            else if (flags & BGAMD_WANT_INDEX) {                // reference-order index + list length (slow path)
                 IndexVisitor iv;
                 iv.t_orig = origins; iv.t_len = (uint32_t)len; iv.t_dA = (uint32_t)dA; iv.t_dB = (uint32_t)dB;
                 walk_sequences(own, opp, c.turn, c.d1, c.d2, iv);
                 chosen = (int32_t)iv.idx; ccount = iv.n;
             } else chosen = 0;                             // "a move was made"; exact index only on request
+            if (!explored) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < len) apply_move(own, opp, c.turn, key_origin(key, k), (k & 1) ? dB : dA);
+                for (int k = 0; k < 4; ++k)
+                    if (k < len) apply_move(own, opp, c.turn, key_origin(key, k), (k & 1) ? dB : dA);
+            }
             cseq = seq_pack(origins, len, dA, dB) | (c.turn ? (1u << 29) : 0u);   // bit 29: mover moves down
         }
         join_sides(own, opp, c.turn, c.p);

@@ -17,6 +17,7 @@
 #include "../../include/bgamd.h"
 #include "bg_board.h"
 #include "bg_eval.h"
+#include "bg_learner.h"
 #include "bg_movegen.h"
 #include "bg_staged.h"
 
@@ -841,7 +842,7 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
     HIPCHK(hipMemsetAsync(&env->sv.tops[T_F], 0, 8, s));
     {
         KTimer t(env, s, 3);
-        hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags);
+        hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags, -1.0f);
         long long b = (n * 64 + 255) / 256;
         const long long lim = (long long)env->n_cu * 8;
         hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
@@ -947,9 +948,18 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     }
     rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
     if (rc) return rc;
+    ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};
+    if (epsilon > 0.0f) {                                  // the leaf-parent list is free again: it holds the tasks
+        KTimer t(env, s, 3);
+        HIPCHK(hipMemsetAsync(&sv.tops[T_F], 0, 8, s));
+        hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags & ~BGAMD_ROLL, epsilon);
+        long long b = (n * 4 + 255) / 256;
+        const long long lim = (long long)env->n_cu * 8;
+        hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
+    }
     {
         KTimer t(env, s, 2);
-        hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags, epsilon);
+        hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, xv, flags, epsilon);
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -1086,6 +1096,227 @@ int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8
         if (h_launches) h_launches[i] = env->t_n[i];
         env->t_ms[i] = 0; env->t_n[i] = 0;
     }
+    return BGAMD_OK;
+}
+
+int bgamd_pack_rows(const int32_t *d_states28, const int32_t *d_turn, int64_t n, void *d_rows, void *stream)
+{
+    if (!d_states28 || !d_rows || n < 0) return BGAMD_E_INVALID;
+    if (n == 0) return BGAMD_OK;
+    hipLaunchKernelGGL(pack_rows_kernel, grid1(n, 128), dim3(128), 0, (hipStream_t)stream, d_states28, d_turn, (long long)n,
+                       (uint4 *)d_rows, (unsigned long long *)nullptr);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+// ------------------------------------------- TD(lambda) learner -------------------------------------------
+}  // extern "C"
+
+struct bgamd_td {
+    int device = 0;
+    long long max_games = 0;
+    TdView v{};
+    bool has_weights = false, begun = false;
+    uint64_t updates = 0;
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double trace_ms = 0;
+    uint64_t trace_launches = 0, trace_game_steps = 0;
+};
+
+namespace {
+int td_flush(bgamd_td *td)
+{
+    for (size_t i = 0; i < td->ev_used; ++i) {
+        HIPCHK(hipEventSynchronize(td->ev[2 * i + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, td->ev[2 * i], td->ev[2 * i + 1]));
+        td->trace_ms += ms;
+    }
+    td->ev_used = 0;
+    return BGAMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
+{
+    if (!out || max_games <= 0 || max_games > (1ll << 22)) return BGAMD_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BGAMD_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    bgamd_td *td = new bgamd_td();
+    td->device = device;
+    td->max_games = max_games;
+    TdView &v = td->v;
+    auto fail = [&](int rc) { bgamd_td_destroy(td); return rc; };
+#define TDALLOC(ptr, bytes)                                                         \
+    do {                                                                            \
+        hipError_t _e = hipMalloc((void **)&(ptr), (size_t)(bytes));                \
+        if (_e != hipSuccess) {                                                     \
+            g_hip_err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(_e); \
+            return fail(BGAMD_E_HIP);                                               \
+        }                                                                           \
+    } while (0)
+    TDALLOC(v.theta, TD_LD * 4);
+    TDALLOC(v.w1t, N_IN * N_HID * 4);
+    TDALLOC(v.e, (size_t)max_games * TD_LD * 4);
+    TDALLOC(v.fac, (size_t)max_games * TD_FLD * 4);
+    TDALLOC(v.coef, (size_t)max_games * 4);
+    TDALLOC(v.sq, (size_t)max_games * 8);
+    TDALLOC(v.partial, (size_t)TD_MAX_GROUPS * TD_LD * 4);
+#undef TDALLOC
+    HIPCHK(hipMemset(v.theta, 0, TD_LD * 4));
+    HIPCHK(hipMemset(v.sq, 0, (size_t)max_games * 8));
+    *out = td;
+    return BGAMD_OK;
+}
+
+int bgamd_td_destroy(bgamd_td *td)
+{
+    if (!td) return BGAMD_OK;
+    hipSetDevice(td->device);
+    hipDeviceSynchronize();
+    TdView &v = td->v;
+    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (hipEvent_t e : td->ev) hipEventDestroy(e);
+    delete td;
+    return BGAMD_OK;
+}
+
+int bgamd_td_set_weights(bgamd_td *td, const float *d_theta, void *stream)
+{
+    if (!td || !d_theta) return BGAMD_E_INVALID;
+    hipLaunchKernelGGL(td_apply_kernel, grid1(TD_P, 256), dim3(256), 0, (hipStream_t)stream, td->v, d_theta, 1);
+    HIPCHK(hipGetLastError());
+    td->has_weights = true;
+    return BGAMD_OK;
+}
+
+int bgamd_td_get_weights(bgamd_td *td, float *d_theta, void *stream)
+{
+    if (!td || !d_theta) return BGAMD_E_INVALID;
+    if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
+    HIPCHK(hipMemcpyAsync(d_theta, td->v.theta, (size_t)TD_P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BGAMD_OK;
+}
+
+int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_order, int64_t n_games,
+                   const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
+{
+    if (!td || !d_rows || !d_order || !d_length || !d_p1_won || T <= 0 || n_lanes <= 0 || n_games < 0 ||
+        n_games > td->max_games || n_games > n_lanes)
+        return BGAMD_E_INVALID;
+    TdView &v = td->v;
+    v.rows = (const uint4 *)d_rows;
+    v.order = d_order;
+    v.length = d_length;
+    v.p1_won = d_p1_won;
+    v.T = T; v.n_lanes = n_lanes; v.n_games = n_games;
+    if (n_games > 0) HIPCHK(hipMemsetAsync(v.sq, 0, (size_t)n_games * 8, (hipStream_t)stream));
+    td->updates = 0;
+    td->begun = true;
+    return BGAMD_OK;
+}
+
+int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream)
+{
+    if (!td || !td->begun || t < 0 || t >= td->v.T || n_active < 0 || n_active > td->v.n_games) return BGAMD_E_INVALID;
+    if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_active == 0) {                 // nothing to add, but the caller's collective still needs a defined buffer
+        if (d_update) HIPCHK(hipMemsetAsync(d_update, 0, (size_t)TD_P * 4, s));
+        return BGAMD_OK;
+    }
+    const TdView &v = td->v;
+    hipLaunchKernelGGL(td_forward_kernel, grid1(n_active, TD_GB), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+    // games per group: >= 4, and at most TD_MAX_GROUPS groups
+    long long ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
+    if (ng < 4) ng = 4;
+    const int n_groups = (int)((n_active + ng - 1) / ng);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (td->timing) {
+        if (td->ev_used * 2 + 2 > td->ev.size()) {
+            if (td->ev.size() >= 2 * 4096) { const int rc = td_flush(td); if (rc) return rc; }
+            else for (int i = 0; i < 2; ++i) { hipEvent_t x; HIPCHK(hipEventCreate(&x)); td->ev.push_back(x); }
+        }
+        e0 = td->ev[2 * td->ev_used]; e1 = td->ev[2 * td->ev_used + 1];
+        td->ev_used++;
+        HIPCHK(hipEventRecord(e0, s));
+    }
+    if (t == 0)
+        hipLaunchKernelGGL(td_trace_kernel<true>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
+                           (int)ng, lambda);
+    else
+        hipLaunchKernelGGL(td_trace_kernel<false>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
+                           (int)ng, lambda);
+    if (td->timing) {
+        HIPCHK(hipEventRecord(e1, s));
+        td->trace_launches++;
+        td->trace_game_steps += (uint64_t)n_active;
+    }
+    hipLaunchKernelGGL(td_reduce_kernel, grid1(TD_P, 64), dim3(256), 0, s, v, n_groups, d_update, d_update ? 0 : 1);
+    HIPCHK(hipGetLastError());
+    td->updates += (uint64_t)n_active;
+    return BGAMD_OK;
+}
+
+int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream)
+{
+    if (!td || !d_update) return BGAMD_E_INVALID;
+    if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
+    hipLaunchKernelGGL(td_apply_kernel, grid1(TD_P, 256), dim3(256), 0, (hipStream_t)stream, td->v, d_update, 0);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream)
+{
+    if (!td || !h_n_active || n_steps < 0 || (td->begun && n_steps > td->v.T)) return BGAMD_E_INVALID;
+    for (int64_t t = 0; t < n_steps; ++t) {
+        if (h_n_active[t] == 0) continue;
+        const int rc = bgamd_td_step(td, t, h_n_active[t], alpha, lambda, nullptr, stream);
+        if (rc != BGAMD_OK) return rc;
+    }
+    return BGAMD_OK;
+}
+
+int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
+{
+    if (!td) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (h_sq_sum) {
+        std::vector<double> sq((size_t)td->v.n_games);
+        if (!sq.empty()) HIPCHK(hipMemcpy(sq.data(), td->v.sq, sq.size() * 8, hipMemcpyDeviceToHost));
+        double acc = 0;
+        for (double x : sq) acc += x;
+        *h_sq_sum = acc;
+    }
+    if (h_updates) *h_updates = (int64_t)td->updates;
+    return BGAMD_OK;
+}
+
+int bgamd_td_time(bgamd_td *td, int enable)
+{
+    if (!td) return BGAMD_E_INVALID;
+    if (!enable && td->timing) { const int rc = td_flush(td); if (rc) return rc; }
+    td->timing = enable != 0;
+    return BGAMD_OK;
+}
+
+int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps)
+{
+    if (!td) return BGAMD_E_INVALID;
+    const int rc = td_flush(td);
+    if (rc) return rc;
+    if (h_trace_ms) *h_trace_ms = td->trace_ms;
+    if (h_launches) *h_launches = td->trace_launches;
+    if (h_game_steps) *h_game_steps = td->trace_game_steps;
+    td->trace_ms = 0; td->trace_launches = 0; td->trace_game_steps = 0;
     return BGAMD_OK;
 }
 

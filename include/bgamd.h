@@ -169,6 +169,42 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
 int bgamd_env_time_kernels(bgamd_env *env, int enable);
 int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8]);
 
+/* states (28 ints, reference getGameBoard layout) + turn -> 32-byte rows, the trajectory log's format */
+int bgamd_pack_rows(const int32_t *d_states28, const int32_t *d_turn, int64_t n, void *d_rows, void *stream);
+
+/* ---- TD(lambda) learner -----------------------------------------------------------------------------
+ * Replaces apply_td_updates (pysrc/TD(λ) model/train.py:124-172) with the eligibility traces of
+ * model.py:48-53 (reset per game, train.py:539-540), as a lock-step replay: step t updates EVERY game that has a
+ * turn t from the same weights, and the per-game updates  fp32(α δ_g) · e_g  are summed (one game = the
+ * reference's own update, step for step; many games = mini-batch TD(λ), the documented deviation).
+ * Weights: flat float[25601] = fc1.weight[128][198] | fc1.bias[128] | fc2.weight[128] | fc2.bias[1].
+ *
+ * begin : d_rows = the env's trajectory log [T][n_lanes] x 32 B; d_order = the n_games lanes to replay, ordered by
+ *         DECREASING d_length[lane] (so the games still running at step t are a prefix of the order);
+ *         d_length[lane] in 1..T = number of logged turns, d_p1_won[lane] = 1 if PLAYER1 won (the terminal target z,
+ *         train.py:165).  The buffers must stay valid until the last step.  Traces start at zero.
+ * step  : step t over the first n_active games of the order: forward of s_t and s_{t+1}, δ = V(s_{t+1}) - V(s_t)
+ *         (z - V(s_t) on a game's last turn), e <- λ e + ∇V(s_t), update = Σ_g fp32(alpha · δ_g) e_g with alpha·δ
+ *         formed in float64 (train.py:147).  d_update == NULL: the update is applied to the weights.  Otherwise it is
+ *         written to d_update[25601] and NOT applied: the caller all-reduces it over the ranks (the one collective
+ *         of a training step) and calls bgamd_td_apply.
+ * replay: steps 0..n_steps-1 with h_n_active[t] games each, applied locally.
+ * stats : Σ δ² and the number of (game, step) updates since begin (synchronises). */
+typedef struct bgamd_td bgamd_td;
+int bgamd_td_create(bgamd_td **out, int64_t max_games, int device);
+int bgamd_td_destroy(bgamd_td *td);
+int bgamd_td_set_weights(bgamd_td *td, const float *d_theta, void *stream);
+int bgamd_td_get_weights(bgamd_td *td, float *d_theta, void *stream);
+int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_order,
+                   int64_t n_games, const int32_t *d_length, const uint8_t *d_p1_won, void *stream);
+int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream);
+int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream);
+int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream);
+int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates);
+/* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1) */
+int bgamd_td_time(bgamd_td *td, int enable);
+int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -694,3 +694,61 @@ def test_reset_lanes_by_mask(bg, O):
     assert (st2[~keep] == np.array(START + [0, 0, 0, 0])).all() and (epi[~keep] == 1).all() and (ply[~keep] == 0).all()
     for lane in np.where(~keep)[0][:40]:
         assert tn2[lane] == O.lib().bgo_opening_turn(55, int(lane) + n)
+
+
+def test_device_learner_single_game_matches_reference_fixture(bg, O, weights, golden_dir):
+    """HIP TD(λ) learner (bgamd_td_*): ONE game replayed step by step equals the reference's apply_td_updates
+    (fixture G6, written by the reference learner), same bar as the host-side closed form: max |Δθ| < 2e-6."""
+    from backgammon_env.learner import DeviceTDLambdaLearner
+    g = np.load(os.path.join(golden_dir, "g6_td_lambda.npz"))
+    st, turn = g["states"].astype(np.int32), g["turn"].astype(np.int32)
+    T = len(st)
+    rows = bg.pack_rows(st, turn).reshape(T, 1, 8)
+    # the packed rows decode to the oracle's encoding
+    env = bg.VecGame(1)
+    X = _np(env.encode_rows(rows))[:, 0]
+    for i in range(T):
+        assert np.array_equal(X[i], O.encode(st[i:i + 1], int(turn[i]))[0])
+    alpha, lam = g["alpha_lambda"]
+    L = DeviceTDLambdaLearner(weights, max_games=4, alpha=alpha, lam=lam)
+    sq, cnt = L.replay_rows(rows, [T], [int(g["winner"][0]) == 0])
+    assert cnt == T
+    w_after = _np(L.theta)
+    assert np.abs(w_after - g["w_after"]).max() < 2e-6
+    assert np.abs(g["w_after"] - weights).max() > 1e-4
+    # the reference reports Σ δ² without the terminal step; ours adds the terminal one (>= 0, <= 1)
+    assert -1e-6 <= sq - float(np.sum(g["losses"])) < 1.0
+    sd = L.state_dict()
+    assert tuple(sd["fc1.weight"].shape) == (128, 198) and tuple(sd["fc2.weight"].shape) == (1, 128)
+
+
+def test_device_learner_round_matches_host_closed_form(bg, O, weights):
+    """A ragged round (games of different lengths, some lanes not replayed) through the HIP learner equals the
+    host-side closed-form replay in float64 on the CPU; the update is deterministic run to run."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n = 200                                               # not a multiple of the kernels' group sizes
+    env = bg.VecGame(n, seed=123)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    lengths = lengths.clone()
+    lengths[::7] = 0                                       # lanes that are not replayed
+    lengths[3] = 1                                         # a one-turn game: only the terminal step
+    ln = _np(lengths)
+    Xr = env.encode_rows(rows).cpu().double()
+    Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.9, dtype=torch.float64)
+    sq_c, cnt_c = Lc.replay(Xr, lengths.cpu(), p1_won.cpu(), batch_scale=0.25)
+    out = []
+    for rep in range(2):
+        Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.9)
+        sq_d, cnt_d = Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.25)
+        out.append(_np(Ld.theta))
+        assert cnt_d == cnt_c == int(ln.sum())
+        assert abs(sq_d - sq_c) < 1e-3 * max(1.0, sq_c)
+    assert np.array_equal(out[0], out[1])
+    moved = np.abs(Lc.theta.numpy() - weights).max()
+    d = np.abs(out[0] - Lc.theta.numpy()).max()
+    assert moved > 1e-3 and d < 2e-5 * max(1.0, moved), (d, moved)
+    # a second round on the same learner object (buffers are reused, traces restart at zero)
+    Ld.set_weights(weights)
+    Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.25)
+    assert np.array_equal(_np(Ld.theta), out[0])
