@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (AUTO_RESET, BF16, F16X2, F32, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
+from ._capi import (AUTO_RESET, BF16, F16X2, F32, F32_DENSE, NO_FLIP, ONLY_P1, ONLY_P2, ROLL, WANT_INDEX, WEIGHTS_SLOT1,  # noqa: F401
                     BgamdError)
 
 __all__ = ["PlayerType", "Player", "Pieces", "Game", "VecGame", "BgamdError", "set_seed", "pack_rows"]
@@ -311,8 +311,8 @@ class VecGame:
     # -- kernel timing (bench.py)
     def time_kernels(self, enable=True, groups=None):
         """groups: iterable of group names to bracket (default: all): enumerate_ordered, eval, apply, step_random,
-        expand, leaves."""
-        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves")
+        expand, leaves, root (the per-game dense pass of the incremental value net)."""
+        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves", "root")
         arg = int(bool(enable))
         if enable and groups is not None:
             arg = sum(1 << names.index(g) for g in groups) << 8
@@ -321,7 +321,7 @@ class VecGame:
     def kernel_times(self):
         ms, n = (C.c_double * 8)(), (C.c_uint64 * 8)()
         _capi.check(self._lib.bgamd_env_kernel_times(self._h, ms, n), "kernel_times")
-        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves")
+        names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves", "root")
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
 
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbgamd.so")
 
 OK = 0
 ROLL, AUTO_RESET, NO_FLIP, WANT_INDEX, ONLY_P1, ONLY_P2, WEIGHTS_SLOT1 = 1, 2, 4, 8, 16, 32, 64
-F32, BF16, F16X2 = 0, 1, 2
+F32, BF16, F16X2, F32_DENSE = 0, 1, 2, 3
 
 # every symbol include/bgamd.h declares: (name, restype, argtypes)
 _P = C.c_void_p

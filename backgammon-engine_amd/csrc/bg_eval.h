@@ -92,6 +92,9 @@ constexpr int EVAL_RED_STRIDE = 33;                                   // floats 
 constexpr int EVAL_RED_FLOATS = 32 * EVAL_RED_STRIDE;                 // per wave
 constexpr int EVAL_LDS_TOTAL = EVAL_LDS_BYTES + (EVAL_THREADS / 64) * EVAL_RED_FLOATS * 4;
 
+// HIDDEN: instead of the value, store -log2(e) x the 128 hidden PRE-activations (W1 x + b1) of every row to values[row*128+n]
+// (the per-game root term of the incremental evaluator below)
+template <bool HIDDEN>
 __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wl, const float *__restrict__ b1, const float *__restrict__ w2,
@@ -192,6 +195,21 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
 
         // epilogue: hidden sigmoid and the dot with W2 over this lane's 4 columns ...
         __builtin_amdgcn_s_setprio(0);
+        if (HIDDEN) {
+            float bb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bb[c] = b1[32 * c + r];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long orow = tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (orow < n_rows) {
+                    float *o = values + orow * N_HID + r;
+                    o[0] = NL2E * (acc0[j] + bb[0]); o[32] = NL2E * (acc1[j] + bb[1]);
+                    o[64] = NL2E * (acc2[j] + bb[2]); o[96] = NL2E * (acc3[j] + bb[3]);
+                }
+            }
+            continue;
+        }
         float part[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -237,6 +255,201 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     if (lane == 0 && ksteps) atomicAdd(&s_ksteps, ksteps);
     __syncthreads();
     if (ksteps_counter && threadIdx.x == 0 && s_ksteps) atomicAdd(ksteps_counter, (unsigned long long)s_ksteps);
+}
+
+// ================================ incremental fp32 evaluator ======================================
+// Every afterstate of a turn differs from the turn's root position in the few points its <= 4 moves touched, and
+// the encoder (model.py:111-144) is a thermometer code: a count that changes by one flips exactly one feature.
+// So with  a_root = W1 x_root + b1  (one dense pass per GAME, eval_rows_f32_kernel<true> on the MFMA pipe),
+//     a_row = a_root + Σ_{changed features f} Δx_f · W1[:, f]        (typically 4-8 columns instead of 198)
+// in fp32 FMAs; hidden sigmoid, W2 dot, output sigmoid and the per-game arg-max are as in the dense kernel.
+// Lane = row (a[128] in registers), W1^T in LDS with a 132-float row stride, each lane's (feature, Δ) list in LDS.
+// The sum is the same real number as the dense chain with a different association: values agree to ~1e-7.
+constexpr int DELTA_THREADS = 1024;                     // 4 waves per SIMD: the kernel lives on latency hiding
+constexpr int DW_STRIDE = 132;                          // floats per feature row of W1^T in LDS
+constexpr int DELTA_W_FLOATS = N_IN * DW_STRIDE;        // 26 136
+constexpr int DELTA_MAX = 16;                           // <= 4 moves x (origin, destination, hit point, bar)
+constexpr int DELTA_LDS_TOTAL = (DELTA_W_FLOATS + N_HID) * 4 + (DELTA_THREADS / 64) * DELTA_MAX * 64 * 2;   // 16-bit list entries
+
+// W1^T for the incremental kernel, pre-multiplied by -log2(e) (the hidden sigmoid is then rcp(1 + exp2(a))); the rows of
+// the borne-off counters (196, 197: x = n/15) also carry the 1/15, so every list entry is a small multiple of 1/2
+inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[198][132]*/)
+{
+    const float NL2E = -1.44269504088896340736f;
+    for (int f = 0; f < N_IN; ++f)
+        for (int n = 0; n < DW_STRIDE; ++n) {
+            float w = n < N_HID ? NL2E * w1[n * N_IN + f] : 0.0f;
+            if (f >= 196) w = w / 15.0f;
+            wt[f * DW_STRIDE + n] = w;
+        }
+}
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// acc += d * w on both halves, IN PLACE (left to itself the compiler renames the 128 loop-carried accumulators
+// every iteration and copies them back)
+__device__ __forceinline__ void pk_fma_acc(f32x2_t &acc, f32x2_t d, f32x2_t w)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(d), "v"(w));
+}
+
+__global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
+    const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
+    unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
+    const float *__restrict__ b2p, const uint4 *__restrict__ root_rows, const float *__restrict__ root_hidden,
+    float *__restrict__ values, const uint2 *__restrict__ info, unsigned long long *__restrict__ best,
+    unsigned long long *__restrict__ delta_counter)
+{
+    extern __shared__ float4 sW[];                       // [198][33] float4, then w2[128], then the lists
+    float *sW2 = reinterpret_cast<float *>(sW) + DELTA_W_FLOATS;
+    uint16_t *sList = reinterpret_cast<uint16_t *>(sW2 + N_HID) + (threadIdx.x >> 6) * (DELTA_MAX * 64);
+    for (int i = threadIdx.x; i < DELTA_W_FLOATS / 4; i += DELTA_THREADS) sW[i] = wt[i];
+    if (threadIdx.x < N_HID) sW2[threadIdx.x] = w2[threadIdx.x];
+    __syncthreads();
+
+    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
+    const long long n_tiles = (n_rows + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (DELTA_THREADS / 64) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (DELTA_THREADS / 64);
+    const float b2 = *b2p;
+    constexpr float NL2E = -1.44269504088896340736f;
+    uint32_t n_delta = 0;
+
+    // software pipeline: the next tile's row + info are in flight while this tile is computed
+    uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
+    uint2 nxi = make_uint2(0u, 0u);
+    if (wave < n_tiles && wave * 64 + lane < n_rows) {
+        const long long r0 = wave * 64 + lane;
+        nx0 = rows[2 * r0]; nx1 = rows[2 * r0 + 1]; nxi = info[r0];
+    }
+    for (long long tile = wave; tile < n_tiles; tile += n_waves) {
+        const long long row = tile * 64 + lane;
+        const bool valid = row < n_rows;
+        const uint2 inf = nxi;                             // (0, 0) for a padding lane: game 0, harmless
+        const uint4 r0 = root_rows[2 * (long long)inf.x], r1 = root_rows[2 * (long long)inf.x + 1];
+        const f32x4_t *ah = reinterpret_cast<const f32x4_t *>(root_hidden + (long long)inf.x * N_HID);
+        f32x4_t nxt[8];                                    // root term, first 32 hidden units
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nxt[j] = ah[j];
+        const uint32_t p[8] = {nx0.x & ~TURN_BIT, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
+        const uint32_t q[8] = {valid ? r0.x & ~TURN_BIT : 0u, valid ? r0.y : 0u, valid ? r0.z : 0u, valid ? r0.w : 0u,
+                               valid ? r1.x : 0u, valid ? r1.y : 0u, valid ? r1.z : 0u, valid ? r1.w : 0u};
+        {
+            const long long nrow = (tile + n_waves) * 64 + lane;
+            nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0); nxi = make_uint2(0u, 0u);
+            if (nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
+        }
+
+        // ---- this lane's (feature, Δ) list: 16-bit entry = feature | (2Δ as int8) << 8; TYPE 0: Δ = m, 1: Δ = m/2,
+        //      2: Δ = m (the W1^T row is pre-divided by 15)
+        uint32_t cnt = 0;
+        uint16_t *lst = sList + lane;
+#pragma unroll
+        for (int e = 0; e < DELTA_MAX; ++e) lst[e * 64] = 0;       // entry 0 = "add 0 x row 0": the apply loop reads blindly
+#define BG_PUSH(F, TYPE, M)                                                                          \
+    {                                                                                                \
+        if (cnt < DELTA_MAX) lst[cnt * 64] = (uint16_t)((uint32_t)(F) | ((uint32_t)(((TYPE) == 1 ? 1 : 2) * (M)) & 255u) << 8); \
+        ++cnt;                                                                                       \
+    }
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const uint32_t b0 = p[4 * sd], b1 = p[4 * sd + 1], b2 = p[4 * sd + 2], b3 = p[4 * sd + 3];
+            const uint32_t c0 = q[4 * sd], c1 = q[4 * sd + 1], c2 = q[4 * sd + 2], c3 = q[4 * sd + 3];
+            const uint32_t diff = (b0 ^ c0) | (b1 ^ c1) | (b2 ^ c2) | (b3 ^ c3);
+            const uint32_t ge_new[3] = {b0 | b1 | b2 | b3, b1 | b2 | b3, (b0 & b1) | b2 | b3};
+            const uint32_t ge_old[3] = {c0 | c1 | c2 | c3, c1 | c2 | c3, (c0 & c1) | c2 | c3};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {               // thermometer features n>=1, n>=2, n>=3: ±1 where the bit flips
+                uint32_t x = (ge_new[k] ^ ge_old[k]) & PTS;
+                while (x) {
+                    const int pos = __ffs(x) - 1; x &= x - 1;
+                    BG_PUSH(8 * (pos - 1) + 4 * sd + k, 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
+                }
+            }
+            uint32_t x4 = diff & PTS & ((b2 | b3) | (c2 | c3)); // (n-3)/2 can only move where n >= 4 before or after
+            const Side sn{{b0, b1, b2, b3}}, so{{c0, c1, c2, c3}};
+            while (x4) {
+                const int pos = __ffs(x4) - 1; x4 &= x4 - 1;
+                const int n1 = count_at(sn, pos), n0 = count_at(so, pos);
+                const int d = (n1 > 3 ? n1 - 3 : 0) - (n0 > 3 ? n0 - 3 : 0);
+                if (d) BG_PUSH(8 * (pos - 1) + 4 * sd + 3, 1, d);
+            }
+            // bar and borne-off counters: PLAYER1 bar = pos 0, off = pos 25; PLAYER2 bar = pos 25, off = pos 0
+            if (diff & 1u) {
+                const int d = count_at(sn, 0) - count_at(so, 0);
+                BG_PUSH(sd == 0 ? 194 : 197, sd == 0 ? 1 : 2, d);
+            }
+            if (diff & (1u << 25)) {
+                const int d = count_at(sn, 25) - count_at(so, 25);
+                BG_PUSH(sd == 0 ? 196 : 195, sd == 0 ? 2 : 1, d);
+            }
+        }
+#undef BG_PUSH
+        if (cnt > DELTA_MAX) cnt = DELTA_MAX;            // cannot happen for a legal turn
+        n_delta += cnt;
+        uint32_t maxcnt = cnt;                             // wave-uniform trip count of the apply loops
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const uint32_t o = __shfl_xor(maxcnt, m, 64); maxcnt = o > maxcnt ? o : maxcnt; }
+        maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 32 hidden units at a time: root term (the next chunk's is in flight meanwhile), a += Δ · W1[:, f] over
+        //      the lane's entries (a lane that has run out reads a zero entry = adds 0 x row 0: the FMAs stay
+        //      unconditional and in place), hidden sigmoid, partial dot with W2
+        float sum = 0.0f;
+        const f32x4_t *w2v = reinterpret_cast<const f32x4_t *>(sW2);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            f32x2_t a[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[2 * j] = nxt[j].lo; a[2 * j + 1] = nxt[j].hi; }
+            if (c < 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = ah[8 * (c + 1) + j];
+            }
+            for (uint32_t e = 0; e < maxcnt; ++e) {
+                const uint32_t ent = lst[e * 64];
+                const float d = 0.5f * (float)(int)(int8_t)(ent >> 8);
+                const f32x4_t *wr = reinterpret_cast<const f32x4_t *>(sW) + (ent & 255u) * (DW_STRIDE / 4) + 8 * c;
+                const f32x2_t d2 = {d, d};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4_t w = wr[j];
+                    pk_fma_acc(a[2 * j], d2, w.lo);
+                    pk_fma_acc(a[2 * j + 1], d2, w.hi);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4_t w = w2v[8 * c + j];
+                sum = __builtin_fmaf(w.x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].x)), sum);
+                sum = __builtin_fmaf(w.y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].y)), sum);
+                sum = __builtin_fmaf(w.z, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].x)), sum);
+                sum = __builtin_fmaf(w.w, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].y)), sum);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const float v = fast_sigmoid(sum + b2);
+            values[row] = v;
+            uint32_t bits = __float_as_uint(v);
+            bits = (inf.y >> 31) ? ~bits : bits;
+            atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
+        }
+    }
+    __shared__ unsigned int s_nd;
+    if (threadIdx.x == 0) s_nd = 0;
+    __syncthreads();
+    {
+        uint32_t t = n_delta;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) t += __shfl_xor(t, m, 64);
+        if (lane == 0 && t) atomicAdd(&s_nd, t);
+    }
+    __syncthreads();
+    if (delta_counter && threadIdx.x == 0 && s_nd) atomicAdd(delta_counter, (unsigned long long)s_nd);
 }
 
 // ================================ bf16 speed mode ================================================

@@ -45,11 +45,21 @@ struct TdView {
     const int32_t *order;                // [n_games] lane index, by decreasing length
     const int32_t *length;               // [n_lanes]
     const uint8_t *p1_won;               // [n_lanes]
+    int4 *gmeta;                         // [max_games] (lane, length, p1_won, 0) by order position: one load, no chain
     long long T, n_lanes, n_games;
 };
 
 __device__ __forceinline__ float td_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
 typedef float td_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void td_gather_kernel(TdView v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n_games) return;
+    const int lane = v.order[i];
+    v.gmeta[i] = make_int4(lane, v.length[lane], v.p1_won[lane] ? 1 : 0, 0);
+    v.sq[i] = 0.0;
+}
 
 // 8 games x {s_t, s_{t+1}} per workgroup of 128 threads
 __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
@@ -61,6 +71,11 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
     __shared__ float gs[TD_GB];
     const int tid = threadIdx.x;
     const long long i0 = (long long)blockIdx.x * TD_GB;
+    // this thread's fc1.weight column set (198 values) is fetched in ONE batch of independent loads -- a single L2
+    // round trip instead of a chain of them -- and the FMAs then run out of registers
+    float w[N_IN];
+#pragma unroll
+    for (int j = 0; j < N_IN; ++j) w[j] = v.w1t[j * N_HID + tid];
 
     // ---- decode: thread = (row r, chunk c of 3 board points) ----
     {
@@ -68,11 +83,11 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const int s = r / TD_GB, g = r % TD_GB;
         const long long i = i0 + g;
         bool live = i < n_active;
-        int lane = 0, len = 0;
+        int lane = 0;
         if (live) {
-            lane = v.order[i];
-            len = v.length[lane];
-            live = (t + s) < len && (t + s) < v.T;        // s_{t+1} does not exist on the terminal step
+            const int4 gm = v.gmeta[i];
+            lane = gm.x;
+            live = (t + s) < gm.y && (t + s) < v.T;       // s_{t+1} does not exist on the terminal step
         }
         uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
@@ -113,43 +128,16 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[r] = b;
     }
-    // fc1.weight streams from L2 in batches of 18 columns, the next batch in flight while this one is used
-    constexpr int WB = 18;                                 // 198 = 11 x 18
-    float wa[WB], wb[WB];
 #pragma unroll
-    for (int k = 0; k < WB; ++k) wa[k] = v.w1t[k * N_HID + n];
-#pragma unroll 1
-    for (int j0 = 0; j0 < N_IN; j0 += 2 * WB) {
-        const bool more = j0 + WB < N_IN;
+    for (int j = 0; j < N_IN; ++j) {
+        const float4 *xr = reinterpret_cast<const float4 *>(&xs[j][0]);
 #pragma unroll
-        for (int k = 0; k < WB; ++k) wb[k] = more ? v.w1t[(j0 + WB + k) * N_HID + n] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < WB; ++k) {
-            const float4 *xr = reinterpret_cast<const float4 *>(&xs[j0 + k][0]);
-#pragma unroll
-            for (int q = 0; q < NR / 4; ++q) {
-                const float4 x4 = xr[q];
-                acc[4 * q + 0] = fmaf(wa[k], x4.x, acc[4 * q + 0]);
-                acc[4 * q + 1] = fmaf(wa[k], x4.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(wa[k], x4.z, acc[4 * q + 2]);
-                acc[4 * q + 3] = fmaf(wa[k], x4.w, acc[4 * q + 3]);
-            }
-        }
-        if (!more) break;
-        const bool more2 = j0 + 2 * WB < N_IN;
-#pragma unroll
-        for (int k = 0; k < WB; ++k) wa[k] = more2 ? v.w1t[(j0 + 2 * WB + k) * N_HID + n] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < WB; ++k) {
-            const float4 *xr = reinterpret_cast<const float4 *>(&xs[j0 + WB + k][0]);
-#pragma unroll
-            for (int q = 0; q < NR / 4; ++q) {
-                const float4 x4 = xr[q];
-                acc[4 * q + 0] = fmaf(wb[k], x4.x, acc[4 * q + 0]);
-                acc[4 * q + 1] = fmaf(wb[k], x4.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(wb[k], x4.z, acc[4 * q + 2]);
-                acc[4 * q + 3] = fmaf(wb[k], x4.w, acc[4 * q + 3]);
-            }
+        for (int q = 0; q < NR / 4; ++q) {
+            const float4 x4 = xr[q];
+            acc[4 * q + 0] = fmaf(w[j], x4.x, acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(w[j], x4.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(w[j], x4.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(w[j], x4.w, acc[4 * q + 3]);
         }
     }
     const float w2 = v.theta[TD_OFF_W2 + n];
@@ -177,11 +165,10 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const long long i = i0 + tid;
         float g = 0.0f;
         if (i < n_active) {
-            const int lane = v.order[i];
-            const int len = v.length[lane];
+            const int4 gm = v.gmeta[i];
             const float val = outs[tid], vnext = outs[TD_GB + tid];
-            const float z = v.p1_won[lane] ? 1.0f : 0.0f;
-            const float delta = (t + 1 >= len) ? z - val : vnext - val;   // lengths never exceed the log (host check)
+            const float z = gm.z ? 1.0f : 0.0f;
+            const float delta = (t + 1 >= gm.y) ? z - val : vnext - val;   // lengths never exceed the log (host check)
             g = val * (1.0f - val);
             v.coef[i] = (float)(alpha * (double)delta);
             v.sq[i] += (double)delta * (double)delta;

@@ -72,6 +72,8 @@ struct StagedView {
     uint4 *u_rows;                        // unique rows
     uint2 *u_info;
     long long cap_rows;
+    uint4 *root_rows;                     // [n] the position every game is in at the start of the step (mover's turn bit)
+    float *root_hidden;                   // [n][128] W1 x_root + b1 (incremental evaluator, bg_eval.h)
     unsigned long long *best;             // [n] (ordered value bits << 32) | ~key ; 0 = no candidate
     unsigned long long *tops;             // [T_COUNT]
 };

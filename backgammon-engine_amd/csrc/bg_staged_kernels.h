@@ -85,7 +85,11 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
             e.traj[t + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
         }
     }
-    if (g < e.n) sv.best[g] = 0ull;
+    if (g < e.n) {
+        sv.best[g] = 0ull;
+        sv.root_rows[2 * g] = make_uint4(c.p[0] | (c.turn ? TURN_BIT : 0u), c.p[1], c.p[2], c.p[3]);
+        sv.root_rows[2 * g + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
+    }
 }
 
 // ---- one ply per launch, with exact de-duplication inside the workgroup ------------------------------

@@ -538,6 +538,7 @@ struct bgamd_env {
     RandomView rv{};
     float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
     float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
+    float4 *d_wt[2] = {nullptr, nullptr};  // W1^T [198][132] for the incremental evaluator
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
     uint2 *d_lut = nullptr;                // count -> 4 bf16 features
@@ -670,6 +671,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
     for (int k = 0; k < 2; ++k) {
         HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
         HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
+        HIPCHK(hipMalloc(&env->d_wt[k], DELTA_W_FLOATS * 4));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
     }
@@ -690,6 +692,8 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&sv.u_rows, (size_t)cap * 32));
         HIPCHK(hipMalloc(&sv.u_info, (size_t)cap * sizeof(uint2)));
         HIPCHK(hipMalloc(&sv.best, n * 8));
+        HIPCHK(hipMalloc(&sv.root_rows, n * 32));
+        HIPCHK(hipMalloc(&sv.root_hidden, n * N_HID * 4));
         HIPCHK(hipMalloc(&sv.tops, T_COUNT * 8));
         HIPCHK(hipMemset(sv.tops, 0, T_COUNT * 8));
         RandomView &rv = env->rv;                    // bounded random-policy step (bg_random_kernels.h)
@@ -699,7 +703,9 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&rv.task_n, n * 4));
     }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
-    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DELTA_LDS_TOTAL));
     return BGAMD_OK;
 }
 
@@ -710,7 +716,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -874,6 +880,9 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(env->d_w[slot], h_weights, N_PARAMS * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(env->d_wl[slot], wl.data(), EVAL_LDS_BYTES, hipMemcpyHostToDevice));
+    std::vector<float> wt((size_t)DELTA_W_FLOATS);
+    relayout_w1_delta(h_weights, wt.data());
+    HIPCHK(hipMemcpy(env->d_wt[slot], wt.data(), DELTA_W_FLOATS * 4, hipMemcpyHostToDevice));
     std::vector<uint16_t> wl16((size_t)K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16(h_weights, wl16.data());
     uint32_t lut[32];
@@ -893,7 +902,8 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
                        const uint4 *rows, float *values, const uint2 *info, unsigned long long *best, hipStream_t s)
 {
     if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
-    if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2) return BGAMD_E_INVALID;
+    if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2 && precision != BGAMD_F32_DENSE)
+        return BGAMD_E_INVALID;
     const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
     if (precision == BGAMD_F16X2) {
         KTimer t(env, s, 1);
@@ -907,7 +917,7 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
                            (const uint4 *)env->d_wl16[slot], (const uint2 *)env->d_lut, b1, w2, b2, values, info, best);
     } else {
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_f32_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
+        hipLaunchKernelGGL(eval_rows_f32_kernel<false>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const float4 *)env->d_wl[slot], b1, w2, b2, values, info, best,
                            n_rows_ptr ? &env->v.counters[C_KSTEPS] : (unsigned long long *)nullptr);
@@ -946,8 +956,27 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         KTimer t(env, s, 5);
         hipLaunchKernelGGL(stage2_kernel<MODE_LEAF>, sgrid2(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
     }
-    rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
-    if (rc) return rc;
+    if (precision == BGAMD_F32) {
+        // incremental fp32 evaluator: one dense pass per GAME for the root term, then a few W1 columns per afterstate
+        const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+        {
+            KTimer t(env, s, 6);
+            hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s,
+                               (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
+                               (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
+                               (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+        }
+        {
+            KTimer t(env, s, 1);
+            hipLaunchKernelGGL(eval_rows_delta_kernel, dim3(env->n_cu), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
+                               (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], 0ll, &env->v.counters[C_ROWS_EVAL],
+                               (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
+                               env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
+        }
+    } else {
+        rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
+        if (rc) return rc;
+    }
     ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     if (epsilon > 0.0f) {                                  // the leaf-parent list is free again: it holds the tasks
         KTimer t(env, s, 3);
@@ -1166,6 +1195,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.fac, (size_t)max_games * TD_FLD * 4);
     TDALLOC(v.coef, (size_t)max_games * 4);
     TDALLOC(v.sq, (size_t)max_games * 8);
+    TDALLOC(v.gmeta, (size_t)max_games * 16);
     TDALLOC(v.partial, (size_t)TD_MAX_GROUPS * TD_LD * 4);
 #undef TDALLOC
     HIPCHK(hipMemset(v.theta, 0, TD_LD * 4));
@@ -1180,7 +1210,7 @@ int bgamd_td_destroy(bgamd_td *td)
     hipSetDevice(td->device);
     hipDeviceSynchronize();
     TdView &v = td->v;
-    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial};
+    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
     delete td;
@@ -1216,7 +1246,10 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
     v.length = d_length;
     v.p1_won = d_p1_won;
     v.T = T; v.n_lanes = n_lanes; v.n_games = n_games;
-    if (n_games > 0) HIPCHK(hipMemsetAsync(v.sq, 0, (size_t)n_games * 8, (hipStream_t)stream));
+    if (n_games > 0) {
+        hipLaunchKernelGGL(td_gather_kernel, grid1(n_games, 256), dim3(256), 0, (hipStream_t)stream, v);
+        HIPCHK(hipGetLastError());
+    }
     td->updates = 0;
     td->begun = true;
     return BGAMD_OK;

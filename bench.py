@@ -108,9 +108,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
     ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
-    ap.add_argument("--precision", choices=("f32", "f16x2", "bf16"), default="f32",
-                    help="value-net arithmetic: f32 = f32 MFMA (headline); f16x2 = f16 hi+lo weight split, fp32 accumulate "
-                         "(also inside the 1e-5 parity bound); bf16 = speed mode outside it")
+    ap.add_argument("--precision", choices=("f32", "f32_dense", "f16x2", "bf16"), default="f32",
+                    help="value-net arithmetic: f32 = fp32 FMAs, incremental hidden layer (headline); f32_dense = the dense fp32 "
+                         "MFMA chain over every afterstate; f16x2 = f16 hi+lo weight split, fp32 accumulate (also inside the "
+                         "1e-5 parity bound); bf16 = speed mode outside it")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -146,7 +147,7 @@ def main():
     env = bg.VecGame(a.games, device=dev_index, seed=SEED, lane_offset=off, lane_stride=stride,
                      arena_rows=a.games * 512)
     env.load_weights(w)
-    prec = {"f32": bg.F32, "bf16": bg.BF16, "f16x2": bg.F16X2}[a.precision]
+    prec = {"f32": bg.F32, "f32_dense": bg.F32_DENSE, "bf16": bg.BF16, "f16x2": bg.F16X2}[a.precision]
     for _ in range(a.burnin + a.warmup):
         env.step_greedy(precision=prec)
     torch.cuda.synchronize()
@@ -194,7 +195,7 @@ def main():
     # the other value-net modes on the same env (untimed region of the contract: extra information only)
     alt = {}
     if world == 1:
-        for name, pm in (("f32", bg.F32), ("f16x2", bg.F16X2), ("bf16", bg.BF16)):
+        for name, pm in (("f32", bg.F32), ("f32_dense", bg.F32_DENSE), ("f16x2", bg.F16X2), ("bf16", bg.BF16)):
             if name == a.precision:
                 continue
             for _ in range(10):
@@ -206,13 +207,14 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             alt[name] = {"env_steps_per_s": round((env.stats()["steps"] - s0) / dt, 1), "ms_per_step": round(10 * dt, 4)}
-        alt["note"] = ("f16x2 = W1 as f16 hi+lo (22 mantissa bits), exact products, fp32 accumulate: max |value - reference| 3e-7, "
+        alt["note"] = ("f32_dense = dense v_mfma_f32_32x32x2_f32 chain over every afterstate (the r01 v6 headline path); "
+                       "f16x2 = W1 as f16 hi+lo (22 mantissa bits), exact products, fp32 accumulate: max |value - reference| 3e-7, "
                        "inside the 1e-5 parity bound like f32; bf16 = speed mode outside it (1.2e-3)")
     out = {
         "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if a.precision == "f32_dense" else a.precision, "data": "synthetic",
         "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
                                "(tdgammonNEW100k weights), auto-reset, Philox dice",
                    "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
@@ -232,18 +234,38 @@ def main():
         # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
         leaves_gbs = (fn_l * 52 + u_l * 40) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
         expand_gbs = (steps_l * 52 + (fn_l + 2 * dn_l) * 8 + dn_l * 44) / (per["expand"] * 1e-3) / 1e9 if per["expand"] else 0.0
-        # executed MFMA work (fp32 kernel): k-steps that are zero for a whole 32-row tile are skipped
         ks_l = st.get("ksteps_executed", 0) / nl
-        exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32" else None
+        peak = PEAK["f32" if a.precision == "f32_dense" else a.precision]
+        ev = {"bound": "mfma", "achieved": round(eval_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(eval_tf / peak, 4),
+              "traffic": None, "avg_ms": round(per["eval"], 4), "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)}
+        if a.precision == "f32":
+            # incremental evaluator: per row (columns added) x 128 FMAs + 128 hidden units x ~6 flop of epilogue; the
+            # per-game root pass is its own kernel (timed in slot "root")
+            exec_tf = (ks_l * 256 + rows_l * 128 * 6) / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+            root_tf = steps_l * FLOP_PER_ROW / (per["root"] * 1e-3) / 1e12 if per.get("root") else 0.0
+            stage_ms = per["eval"] + per.get("root", 0.0)
+            ev.update({"kernel": "eval_rows_delta_kernel", "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
+                       "executed_tflops": round(exec_tf, 2), "root_pass_kernel": "eval_rows_f32_kernel<true>",
+                       "root_pass_avg_ms": round(per.get("root", 0.0), 4), "root_pass_tflops": round(root_tf, 2),
+                       "root_pass_frac_of_peak": round(root_tf / peak, 4),
+                       "value_net_stage_ms": round(stage_ms, 4),
+                       "value_net_stage_tflops": round(u_l * FLOP_PER_ROW / (stage_ms * 1e-3) / 1e12, 2) if stage_ms else None,
+                       "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d: the flops of the DENSE "
+                               "198->128->1 net). frac exceeds 1 because the kernel does not do the dense work: an afterstate "
+                               "differs from its game's root in a few thermometer features, so its hidden layer is the root's "
+                               "(one dense f32 MFMA pass per game, root_pass_*) plus w1_columns_per_row columns of W1 in fp32 "
+                               "FMAs; executed_tflops is the arithmetic actually issued. The kernel is bound by LDS gathers of "
+                               "W1 columns (one 512 B column per row and changed feature), not by HBM or the MFMA pipe"})
+        else:
+            exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
+            ev.update({"kernel": "eval_rows_%s_kernel" % ("f32" if a.precision == "f32_dense" else a.precision),
+                       "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
+                       "executed_frac_of_peak": round(exec_tf / peak, 4) if exec_tf else None,
+                       "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
+                       "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d); frac can exceed 1 because the "
+                               "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"})
         roofs = {
-            "eval": {"kernel": "eval_rows_%s_kernel" % a.precision, "bound": "mfma", "achieved": round(eval_tf, 3), "peak": PEAK[a.precision],
-                     "unit": "TFLOP/s", "frac": round(eval_tf / PEAK[a.precision], 4), "traffic": None, "avg_ms": round(per["eval"], 4),
-                     "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
-                     "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
-                     "executed_frac_of_peak": round(exec_tf / PEAK[a.precision], 4) if exec_tf else None,
-                     "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
-                     "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d); frac can exceed 1 because the "
-                             "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"},
+            "eval": ev,
             "leaves": {"kernel": "leaves_kernel", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
             "expand": {"kernel": "roots_kernel+expand_kernel<1,2>", "bound": "hbm", "achieved": round(expand_gbs, 2),
@@ -254,7 +276,7 @@ def main():
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            for name, key in (("eval", "eval_rows_%s_kernel" % a.precision), ("leaves", "stage2_kernel<3>")):
+            for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "stage2_kernel<3>")):
                 if key in pmc:
                     roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
                     roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per launch)"
@@ -263,7 +285,7 @@ def main():
         dom = max(roofs, key=lambda k: roofs[k]["avg_ms"])
         out["roofline"] = roofs[dom]
         out["kernels"] = dict(roofs, apply_avg_ms=round(per["apply"], 4),
-                              gpu_ms_per_step=round(per["eval"] + per["leaves"] + per["expand"] + per["apply"], 4))
+                              gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
     if alt:
         out["alt_modes"] = alt
     if world == 1 and not a.no_cpu_baseline:

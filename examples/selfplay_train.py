@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end rehearsal of configs 4/5 on ONE GPU: batched self-play with the turn log, lock-step TD(λ)
-replay (PyTorch-ROCm), weights back into the env; win rate against a uniformly random mover before and after.
+replay (HIP learner kernels, bgamd_td_*; --host-learner = the PyTorch closed form), weights back into the env; win rate against a uniformly random mover before and after.
 Not the reference's training CLI (out of scope) -- a 60-line demonstration that the pieces compose.
 
     python examples/selfplay_train.py --games 512 --rounds 120
@@ -19,7 +19,7 @@ import torch  # noqa: E402
 
 import backgammon_env as bg  # noqa: E402
 from backgammon_env.arena import head_to_head  # noqa: E402
-from backgammon_env.learner import TDLambdaLearner, play_round  # noqa: E402
+from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round  # noqa: E402
 
 
 def xavier_init(seed=0):
@@ -36,16 +36,24 @@ def main():
     ap.add_argument("--games", type=int, default=512, help="games per round (one per lane)")
     ap.add_argument("--rounds", type=int, default=120)
     ap.add_argument("--eps", type=float, default=0.05)
+    ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
     a = ap.parse_args()
     env, arena = bg.VecGame(a.games, seed=1), bg.VecGame(1024, seed=2)
-    L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
+    if a.host_learner:
+        L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
+    else:
+        L = DeviceTDLambdaLearner(xavier_init(), max_games=a.games, alpha=0.1, lam=0.7)
     print("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
     t0, turns = time.time(), 0
     for r in range(a.rounds):
         L.update_learning_params(r * a.games)
         env.load_weights(L.theta.cpu().numpy())
         rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=a.eps)
-        sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, batch_scale=min(1.0, 24.0 / a.games))
+        scale = min(1.0, 24.0 / a.games)
+        if a.host_learner:
+            sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, batch_scale=scale)
+        else:
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=scale)
         turns += cnt
         if r % 20 == 19:
             print(f"round {r + 1}: {(r + 1) * a.games} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "

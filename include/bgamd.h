@@ -54,10 +54,13 @@ enum {
     BGAMD_WEIGHTS_SLOT1 = 64  /* greedy step evaluates with weight slot 1 instead of slot 0        */
 };
 
-/* value-net arithmetic.  F32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).  F16X2: W1 split into f16 hi + lo
+/* value-net arithmetic.  F32: fp32 FMAs throughout.  In a greedy step the hidden layer is evaluated INCREMENTALLY:
+ * one dense v_mfma_f32_32x32x2_f32 pass per game for the root position, then  a_row = a_root + Σ Δx_f · W1[:, f]
+ * over the few features an afterstate changes (same real sum as the dense chain, different association, values
+ * agree to ~1e-7).  F32_DENSE: the dense MFMA chain over every afterstate (what bgamd_evaluate always uses).  F16X2: W1 split into f16 hi + lo
  * (22 mantissa bits), exact products, fp32 accumulation on v_mfma_f32_32x32x16_f16 -- fp32-grade values (inside
  * the 1e-5 parity bound) on the fast matrix pipe.  BF16: single bf16 weights, speed mode outside the bound. */
-enum { BGAMD_F32 = 0, BGAMD_BF16 = 1, BGAMD_F16X2 = 2 };
+enum { BGAMD_F32 = 0, BGAMD_BF16 = 1, BGAMD_F16X2 = 2, BGAMD_F32_DENSE = 3 };
 
 int bgamd_version(void);
 const char *bgamd_error_string(int code);
@@ -129,6 +132,8 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
 int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq /*[n,4,2]*/,
                           int32_t *d_seq_len, float *d_value, void *stream);
 
+/* (slot 8 below counts the 32-row x 2-feature MFMA steps of the dense f32 net, or the W1 columns added by the
+ * incremental one) */
 /* counters since create/reset_stats (synchronises): [steps, games_finished, p1_wins, candidates_raw,
  * rows_evaluated, error_flags, leaf_parent_nodes, doubles_inner_nodes, ksteps_executed (fp32 value net:
  * 32-row x 2-feature MFMA steps actually issued, of 99 per tile), reserved] */
@@ -164,7 +169,7 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
 /* kernel timing hook for bench.py: brackets kernel groups with HIP events on the launch stream;
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
  * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
- * 4 roots+expand (plies 1-3), 5 leaves+dedup.  enable: 0 = off, 1 = every group, (mask << 8) = only the groups
+ * 4 roots+expand (plies 1-3), 5 leaves+dedup, 6 root term of the incremental value net.  enable: 0 = off, 1 = every group, (mask << 8) = only the groups
  * whose bit is set in mask (each bracket costs two event records, ~2-3 us per step). */
 int bgamd_env_time_kernels(bgamd_env *env, int enable);
 int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8]);

@@ -752,3 +752,33 @@ def test_device_learner_round_matches_host_closed_form(bg, O, weights):
     Ld.set_weights(weights)
     Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.25)
     assert np.array_equal(_np(Ld.theta), out[0])
+
+
+def test_incremental_value_net_equals_dense_chain(bg, O, weights):
+    """BGAMD_F32 evaluates the hidden layer incrementally (root term per game + the W1 columns of the features an
+    afterstate changes); BGAMD_F32_DENSE runs the dense fp32 MFMA chain over every afterstate.  Same positions, same
+    dice: the chosen values agree to fp32 rounding (the two differ only in the association of one sum), the chosen
+    moves are the same except at ties inside that rounding, and both are value-optimal for the oracle (1e-5)."""
+    n = 4096
+    for burn, seed in ((0, 11), (9, 12), (40, 13)):
+        a, b = bg.VecGame(n, seed=seed), bg.VecGame(n, seed=seed)
+        a.load_weights(weights); b.load_weights(weights)
+        for _ in range(burn):
+            a.step_random(); b.step_random()
+        pre, pt = _np(a.states()), _np(a.turns())
+        assert np.array_equal(pre, _np(b.states()))
+        a.step_greedy(auto_reset=False, precision=bg.F32)
+        b.step_greedy(auto_reset=False, precision=bg.F32_DENSE)
+        ca, cb = a.last_choice(), b.last_choice()
+        va, vb = _np(ca["value"]), _np(cb["value"])
+        moved = _np(ca["count"]) > 0
+        assert np.array_equal(moved, _np(cb["count"]) > 0)
+        assert np.abs(va[moved] - vb[moved]).max() < 2e-6
+        sa, sb = _np(a.states()), _np(b.states())
+        same = (sa == sb).all(axis=1)
+        assert same.mean() > 0.995, same.mean()
+        dice = _np(a.dice())
+        lanes = [int(l) for l in np.nonzero(~same)[0][:40]] + list(range(0, n, 97))
+        _check_greedy_step(O, weights, pre, pt, dice, sa, lanes)
+        _check_greedy_step(O, weights, pre, pt, dice, sb, lanes)
+        assert a.stats()["error_flags"] == 0
