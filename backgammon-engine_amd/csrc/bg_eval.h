@@ -591,6 +591,122 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_bf16_kernel(
     }
 }
 
+// ================================ bf16 x 3 split: the root term of the incremental evaluator =====================
+// An fp32 weight is EXACTLY hi + mid + lo with three bf16 terms (8 + 8 + 8 significand bits, fp32's exponent range),
+// and every encoder feature is exact in bf16 once the borne-off counters are fed as integers (their W1 rows carry
+// the 1/15).  So  W1 x  is three v_mfma_f32_32x32x16_bf16 per (K-step, column tile) with exact products and fp32
+// accumulation -- fp32-grade results at 3/16 of the fp32 MFMA's cost.  Used for the one dense pass per GAME
+// (root positions); output = -log2(e) (W1 x + b1), what eval_rows_delta_kernel starts from.
+// The three weight planes (160 KB) do not fit LDS together: K is staged in two phases (7 + 6 K-steps).
+constexpr int ROOT3_THREADS = 512;
+constexpr int ROOT3_PHASE_STEPS = 7;
+constexpr int ROOT3_PART_U4 = K16_STEPS * 4 * 64;                                  // uint4 per weight plane
+constexpr int ROOT3_LDS_TOTAL = 3 * ROOT3_PHASE_STEPS * 4 * 64 * 16 + EVAL16_LUT_BYTES;   // 86 144
+
+// Wl[part][s][c][l][j]; tail step = [turn0, turn1, bar1/2, bar2/2, off1, off2, 0, 0] with rows 196/197 divided by 15
+inline void relayout_w1_bf16x3(const float *w1, uint16_t *wl)
+{
+    static const int tail_map[8] = {192, 193, 194, 195, 196, 197, -1, -1};
+    for (int s = 0; s < K16_STEPS; ++s)
+        for (int c = 0; c < 4; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    int f = 16 * s + 8 * (l >> 5) + j;
+                    if (s == 12) f = (l >> 5) == 0 ? tail_map[j] : -1;
+                    float w = f >= 0 && f < N_IN ? w1[(32 * c + (l & 31)) * N_IN + f] : 0.0f;
+                    if (f >= 196) w = w / 15.0f;
+                    const size_t o = (((size_t)s * 4 + c) * 64 + l) * 8 + j;
+                    for (int part = 0; part < 3; ++part) {
+                        const uint16_t b = f32_to_bf16_rne(w);
+                        union { uint32_t u; float f; } cv;
+                        cv.u = (uint32_t)b << 16;
+                        w -= cv.f;                                             // exact: the residual fits fp32
+                        wl[(size_t)part * ROOT3_PART_U4 * 8 + o] = b;
+                    }
+                }
+}
+
+__global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
+    const uint4 *__restrict__ rows, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
+    const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    extern __shared__ uint4 sW3[];                          // [3][ROOT3_PHASE_STEPS][4][64]
+    uint2 *sLut = reinterpret_cast<uint2 *>(sW3 + 3 * ROOT3_PHASE_STEPS * 4 * 64);
+    if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
+    const long long n_tiles = (n_rows + 31) >> 5;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const long long wave = (long long)blockIdx.x * (ROOT3_THREADS / 64) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (ROOT3_THREADS / 64);
+    constexpr float NL2E = -1.44269504088896340736f;
+    constexpr int PH = ROOT3_PHASE_STEPS * 4 * 64;          // uint4 per plane and phase
+
+    for (long long base = 0; base < n_tiles; base += n_waves) {          // every wave of the block runs every round
+        const long long tile = base + wave;
+        const bool has = tile < n_tiles;
+        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (has && tile * 32 + r < n_rows) {
+            const uint4 u0 = rows[2 * (tile * 32 + r)], u1 = rows[2 * (tile * 32 + r) + 1];
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+        const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+        floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            const int s0 = phase * ROOT3_PHASE_STEPS;
+            const int ns = phase == 0 ? ROOT3_PHASE_STEPS : K16_STEPS - ROOT3_PHASE_STEPS;
+            __syncthreads();                                 // the previous phase's readers are done
+            for (int i = threadIdx.x; i < 3 * ns * 4 * 64; i += ROOT3_THREADS) {
+                const int part = i / (ns * 4 * 64), o = i - part * (ns * 4 * 64);
+                sW3[part * PH + o] = wl3[(size_t)part * ROOT3_PART_U4 + (size_t)s0 * 4 * 64 + o];
+            }
+            __syncthreads();
+            if (has) {
+                const uint4 *wp = sW3 + lane;
+                for (int k = 0; k < ns; ++k) {
+                    const int s = s0 + k;
+                    union { uint4 u; bf16x8 v; } a;
+                    if (s < 12) {
+                        const int pos = 2 * s + h + 1;
+                        const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+                        a.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    } else {                                 // features 192..197 on the h == 0 lanes; off counts as integers
+                        const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+                        const uint32_t t0 = turn == 0 ? 0x3F80u : 0u, t1 = turn == 0 ? 0u : 0x3F80u;
+                        const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+                        const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+                        a.u = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+                    }
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+                        union { uint4 u; bf16x8 v; } w0, w1, w2r, w3;
+                        const uint4 *q = wp + part * PH + k * 4 * 64;
+                        w0.u = q[0]; w1.u = q[64]; w2r.u = q[128]; w3.u = q[192];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, w0.v, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, w1.v, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, w2r.v, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, w3.v, acc3, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (has) {
+            float bb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bb[c] = b1[32 * c + r];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long orow = tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (orow < n_rows) {
+                    float *o = hidden + orow * N_HID + r;
+                    o[0] = NL2E * (acc0[j] + bb[0]); o[32] = NL2E * (acc1[j] + bb[1]);
+                    o[64] = NL2E * (acc2[j] + bb[2]); o[96] = NL2E * (acc3[j] + bb[3]);
+                }
+            }
+        }
+    }
+}
+
 // ================================ f16 x 2 split: fp32-grade values on the fast matrix pipe ================
 // W1 = hi + lo with hi = f16(W1), lo = f16(W1 - hi): 22 mantissa bits, |error| <= 2^-22 |w| + 3e-8.  Every
 // feature is exact in f16 except off/15, which is fed as its own hi + lo pair, so each product is exact in

@@ -10,6 +10,7 @@
 // Random step: rnd_tasks -> rnd_count -> rnd_select (bg_random_kernels.h).  emit_kernel serves the ordered enumerate API.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -539,12 +540,14 @@ struct bgamd_env {
     float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
     float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
     float4 *d_wt[2] = {nullptr, nullptr};  // W1^T [198][132] for the incremental evaluator
+    uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term)
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
     uint2 *d_lut = nullptr;                // count -> 4 bf16 features
     uint2 *d_lut16 = nullptr;              // count -> 4 f16 features
     bool has_weights[2] = {false, false};
     int n_cu = 256;
+    bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
     std::vector<hipEvent_t> ev;            // pairs
@@ -640,6 +643,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         g_hip_err = why;
         return rc;
     }
+    env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
     *out = env;
     return BGAMD_OK;
 }
@@ -672,6 +676,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
         HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
         HIPCHK(hipMalloc(&env->d_wt[k], DELTA_W_FLOATS * 4));
+        HIPCHK(hipMalloc(&env->d_wl3[k], 3 * EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
     }
@@ -706,6 +711,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DELTA_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)root_hidden_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROOT3_LDS_TOTAL));
     return BGAMD_OK;
 }
 
@@ -716,7 +722,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->sv.root_rows, env->sv.root_hidden,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
@@ -883,6 +889,9 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     std::vector<float> wt((size_t)DELTA_W_FLOATS);
     relayout_w1_delta(h_weights, wt.data());
     HIPCHK(hipMemcpy(env->d_wt[slot], wt.data(), DELTA_W_FLOATS * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> wl3((size_t)3 * K16_STEPS * 4 * 64 * 8);
+    relayout_w1_bf16x3(h_weights, wl3.data());
+    HIPCHK(hipMemcpy(env->d_wl3[slot], wl3.data(), 3 * EVAL16_W_BYTES, hipMemcpyHostToDevice));
     std::vector<uint16_t> wl16((size_t)K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16(h_weights, wl16.data());
     uint32_t lut[32];
@@ -961,10 +970,18 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
         {
             KTimer t(env, s, 6);
-            hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s,
-                               (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
-                               (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
-                               (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+            if (env->root_f32_mfma)
+                hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s,
+                                   (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
+                                   (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
+                                   (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+            else {
+                long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
+                if (blocks > env->n_cu) blocks = env->n_cu;
+                hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
+                                   ROOT3_LDS_TOTAL, s, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
+                                   (const uint2 *)env->d_lut, b1, sv.root_hidden);
+            }
         }
         {
             KTimer t(env, s, 1);

@@ -762,9 +762,15 @@ def test_incremental_value_net_equals_dense_chain(bg, O, weights):
     n = 4096
     for burn, seed in ((0, 11), (9, 12), (40, 13)):
         a, b = bg.VecGame(n, seed=seed), bg.VecGame(n, seed=seed)
-        a.load_weights(weights); b.load_weights(weights)
+        os.environ["BGAMD_ROOT_F32"] = "1"             # third env: root term by the f32 MFMA chain instead of bf16 x 3
+        try:
+            c = bg.VecGame(n, seed=seed)
+        finally:
+            del os.environ["BGAMD_ROOT_F32"]
+        a.load_weights(weights); b.load_weights(weights); c.load_weights(weights)
         for _ in range(burn):
-            a.step_random(); b.step_random()
+            a.step_random(); b.step_random(); c.step_random()
+        c.step_greedy(auto_reset=False, precision=bg.F32)
         pre, pt = _np(a.states()), _np(a.turns())
         assert np.array_equal(pre, _np(b.states()))
         a.step_greedy(auto_reset=False, precision=bg.F32)
@@ -774,6 +780,9 @@ def test_incremental_value_net_equals_dense_chain(bg, O, weights):
         moved = _np(ca["count"]) > 0
         assert np.array_equal(moved, _np(cb["count"]) > 0)
         assert np.abs(va[moved] - vb[moved]).max() < 2e-6
+        vc = _np(c.last_choice()["value"])
+        assert np.abs(va[moved] - vc[moved]).max() < 1e-6      # bf16 x 3 root term == f32 MFMA root term (fp32 rounding)
+        assert ((_np(c.states()) == _np(a.states())).all(axis=1)).mean() > 0.995
         sa, sb = _np(a.states()), _np(b.states())
         same = (sa == sb).all(axis=1)
         assert same.mean() > 0.995, same.mean()
