@@ -263,24 +263,31 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
 // So with  a_root = W1 x_root + b1  (one dense pass per GAME, eval_rows_f32_kernel<true> on the MFMA pipe),
 //     a_row = a_root + Σ_{changed features f} Δx_f · W1[:, f]        (typically 4-8 columns instead of 198)
 // in fp32 FMAs; hidden sigmoid, W2 dot, output sigmoid and the per-game arg-max are as in the dense kernel.
-// Lane = row (a[128] in registers), W1^T in LDS with a 132-float row stride, each lane's (feature, Δ) list in LDS.
+// Lane = row, 32 hidden units at a time in registers, W1^T in LDS (132-float row stride), each lane's (row, Δ) list in LDS.
 // The sum is the same real number as the dense chain with a different association: values agree to ~1e-7.
 constexpr int DELTA_THREADS = 1024;                     // 4 waves per SIMD: the kernel lives on latency hiding
 constexpr int DW_STRIDE = 132;                          // floats per feature row of W1^T in LDS
-constexpr int DELTA_W_FLOATS = N_IN * DW_STRIDE;        // 26 136
+// Row of feature f in the LDS table: 9 * point + (4 * side + level) for the board features, 216.. for the tail.  The
+// LDS bank class of a 16-byte read is (row + chunk) mod 8; candidates of one game mostly differ in WHICH point a
+// checker left or reached at the same thermometer level, and with row = f (= 8 * point + level) all those lanes
+// hit the same banks (measured: half of all LDS cycles were conflict cycles).  9 * point spreads them.
+constexpr int DW_ROWS = 9 * 24 + 6;                     // 222
+__host__ __device__ constexpr int delta_row(int f) { return f < 192 ? 9 * (f >> 3) + (f & 7) : 216 + (f - 192); }
+constexpr int DELTA_W_FLOATS = DW_ROWS * DW_STRIDE;     // 29 304
 constexpr int DELTA_MAX = 16;                           // <= 4 moves x (origin, destination, hit point, bar)
 constexpr int DELTA_LDS_TOTAL = (DELTA_W_FLOATS + N_HID) * 4 + (DELTA_THREADS / 64) * DELTA_MAX * 64 * 2;   // 16-bit list entries
 
 // W1^T for the incremental kernel, pre-multiplied by -log2(e) (the hidden sigmoid is then rcp(1 + exp2(a))); the rows of
 // the borne-off counters (196, 197: x = n/15) also carry the 1/15, so every list entry is a small multiple of 1/2
-inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[198][132]*/)
+inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[DW_ROWS][132]*/)
 {
     const float NL2E = -1.44269504088896340736f;
+    for (int i = 0; i < DELTA_W_FLOATS; ++i) wt[i] = 0.0f;
     for (int f = 0; f < N_IN; ++f)
-        for (int n = 0; n < DW_STRIDE; ++n) {
-            float w = n < N_HID ? NL2E * w1[n * N_IN + f] : 0.0f;
+        for (int n = 0; n < N_HID; ++n) {
+            float w = NL2E * w1[n * N_IN + f];
             if (f >= 196) w = w / 15.0f;
-            wt[f * DW_STRIDE + n] = w;
+            wt[delta_row(f) * DW_STRIDE + n] = w;
         }
 }
 
@@ -293,6 +300,51 @@ __device__ __forceinline__ void pk_fma_acc(f32x2_t &acc, f32x2_t d, f32x2_t w)
     asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(d), "v"(w));
 }
 
+// One list entry for 32 hidden units: a[0..15] += d * W1^T[row][32c .. 32c+31], the 8 ds_read_b128 software-pipelined by
+// hand (four reads in flight, FMAs issued as each lands).  The compiler, short of registers at 4 waves per SIMD,
+// serialised the reads with full lgkmcnt(0) waits; the temporaries here are the fixed registers v[108:127].
+__device__ __forceinline__ void delta_apply_32(f32x2_t (&a)[16], f32x2_t d2, uint32_t lds_addr)
+{
+    asm volatile(
+        "ds_read_b128 v[108:111], %17\n\t"
+        "ds_read_b128 v[112:115], %17 offset:16\n\t"
+        "ds_read_b128 v[116:119], %17 offset:32\n\t"
+        "ds_read_b128 v[120:123], %17 offset:48\n\t"
+        "ds_read_b128 v[124:127], %17 offset:64\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_pk_fma_f32 %0, %16, v[108:109], %0\n\t"
+        "v_pk_fma_f32 %1, %16, v[110:111], %1\n\t"
+        "ds_read_b128 v[108:111], %17 offset:80\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_pk_fma_f32 %2, %16, v[112:113], %2\n\t"
+        "v_pk_fma_f32 %3, %16, v[114:115], %3\n\t"
+        "ds_read_b128 v[112:115], %17 offset:96\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_pk_fma_f32 %4, %16, v[116:117], %4\n\t"
+        "v_pk_fma_f32 %5, %16, v[118:119], %5\n\t"
+        "ds_read_b128 v[116:119], %17 offset:112\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_pk_fma_f32 %6, %16, v[120:121], %6\n\t"
+        "v_pk_fma_f32 %7, %16, v[122:123], %7\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_pk_fma_f32 %8, %16, v[124:125], %8\n\t"
+        "v_pk_fma_f32 %9, %16, v[126:127], %9\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_pk_fma_f32 %10, %16, v[108:109], %10\n\t"
+        "v_pk_fma_f32 %11, %16, v[110:111], %11\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_pk_fma_f32 %12, %16, v[112:113], %12\n\t"
+        "v_pk_fma_f32 %13, %16, v[114:115], %13\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %14, %16, v[116:117], %14\n\t"
+        "v_pk_fma_f32 %15, %16, v[118:119], %15"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(d2), "v"(lds_addr)
+        : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
+          "v122", "v123", "v124", "v125", "v126", "v127", "memory");
+}
+
 __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
@@ -300,7 +352,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     float *__restrict__ values, const uint2 *__restrict__ info, unsigned long long *__restrict__ best,
     unsigned long long *__restrict__ delta_counter)
 {
-    extern __shared__ float4 sW[];                       // [198][33] float4, then w2[128], then the lists
+    extern __shared__ float4 sW[];                       // [DW_ROWS][33] float4, then w2[128], then the lists
     float *sW2 = reinterpret_cast<float *>(sW) + DELTA_W_FLOATS;
     uint16_t *sList = reinterpret_cast<uint16_t *>(sW2 + N_HID) + (threadIdx.x >> 6) * (DELTA_MAX * 64);
     for (int i = threadIdx.x; i < DELTA_W_FLOATS / 4; i += DELTA_THREADS) sW[i] = wt[i];
@@ -324,15 +376,21 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         const long long r0 = wave * 64 + lane;
         nx0 = rows[2 * r0]; nx1 = rows[2 * r0 + 1]; nxi = info[r0];
     }
+    // ... and so are its game's root row and the first 32 hidden units of the root term (issued during the LAST chunk
+    // of the tile before: a tile otherwise starts with two dependent memory round trips and nothing to overlap them)
+    uint4 nr0 = root_rows[2 * (long long)nxi.x], nr1 = root_rows[2 * (long long)nxi.x + 1];
+    f32x4_t nxt[8];
+    {
+        const f32x4_t *ah0 = reinterpret_cast<const f32x4_t *>(root_hidden + (long long)nxi.x * N_HID);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nxt[j] = ah0[j];
+    }
     for (long long tile = wave; tile < n_tiles; tile += n_waves) {
         const long long row = tile * 64 + lane;
         const bool valid = row < n_rows;
         const uint2 inf = nxi;                             // (0, 0) for a padding lane: game 0, harmless
-        const uint4 r0 = root_rows[2 * (long long)inf.x], r1 = root_rows[2 * (long long)inf.x + 1];
+        const uint4 r0 = nr0, r1 = nr1;
         const f32x4_t *ah = reinterpret_cast<const f32x4_t *>(root_hidden + (long long)inf.x * N_HID);
-        f32x4_t nxt[8];                                    // root term, first 32 hidden units
-#pragma unroll
-        for (int j = 0; j < 8; ++j) nxt[j] = ah[j];
         const uint32_t p[8] = {nx0.x & ~TURN_BIT, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
         const uint32_t q[8] = {valid ? r0.x & ~TURN_BIT : 0u, valid ? r0.y : 0u, valid ? r0.z : 0u, valid ? r0.w : 0u,
                                valid ? r1.x : 0u, valid ? r1.y : 0u, valid ? r1.z : 0u, valid ? r1.w : 0u};
@@ -365,7 +423,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 uint32_t x = (ge_new[k] ^ ge_old[k]) & PTS;
                 while (x) {
                     const int pos = __ffs(x) - 1; x &= x - 1;
-                    BG_PUSH(8 * (pos - 1) + 4 * sd + k, 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
+                    BG_PUSH(9 * (pos - 1) + 4 * sd + k, 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
                 }
             }
             uint32_t x4 = diff & PTS & ((b2 | b3) | (c2 | c3)); // (n-3)/2 can only move where n >= 4 before or after
@@ -374,16 +432,16 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 const int pos = __ffs(x4) - 1; x4 &= x4 - 1;
                 const int n1 = count_at(sn, pos), n0 = count_at(so, pos);
                 const int d = (n1 > 3 ? n1 - 3 : 0) - (n0 > 3 ? n0 - 3 : 0);
-                if (d) BG_PUSH(8 * (pos - 1) + 4 * sd + 3, 1, d);
+                if (d) BG_PUSH(9 * (pos - 1) + 4 * sd + 3, 1, d);
             }
             // bar and borne-off counters: PLAYER1 bar = pos 0, off = pos 25; PLAYER2 bar = pos 25, off = pos 0
             if (diff & 1u) {
                 const int d = count_at(sn, 0) - count_at(so, 0);
-                BG_PUSH(sd == 0 ? 194 : 197, sd == 0 ? 1 : 2, d);
+                BG_PUSH(delta_row(sd == 0 ? 194 : 197), sd == 0 ? 1 : 2, d);
             }
             if (diff & (1u << 25)) {
                 const int d = count_at(sn, 25) - count_at(so, 25);
-                BG_PUSH(sd == 0 ? 196 : 195, sd == 0 ? 2 : 1, d);
+                BG_PUSH(delta_row(sd == 0 ? 196 : 195), sd == 0 ? 2 : 1, d);
             }
         }
 #undef BG_PUSH
@@ -400,26 +458,26 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         //      unconditional and in place), hidden sigmoid, partial dot with W2
         float sum = 0.0f;
         const f32x4_t *w2v = reinterpret_cast<const f32x4_t *>(sW2);
+        const uint32_t sW_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)sW;   // LDS byte address
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             f32x2_t a[16];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a[2 * j] = nxt[j].lo; a[2 * j + 1] = nxt[j].hi; }
-            if (c < 3) {
+            {   // next 32 units of this tile, or (last chunk) the next tile's root row and first 32 units
+                const f32x4_t *src = c < 3 ? ah + 8 * (c + 1)
+                                           : reinterpret_cast<const f32x4_t *>(root_hidden + (long long)nxi.x * N_HID);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nxt[j] = ah[8 * (c + 1) + j];
+                for (int j = 0; j < 8; ++j) nxt[j] = src[j];
+                if (c == 3) { nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1]; }
             }
+            uint32_t ent = lst[0];
             for (uint32_t e = 0; e < maxcnt; ++e) {
-                const uint32_t ent = lst[e * 64];
+                const uint32_t nent = lst[(e + 1 < DELTA_MAX ? e + 1 : e) * 64];      // next entry: its LDS latency hides here
                 const float d = 0.5f * (float)(int)(int8_t)(ent >> 8);
-                const f32x4_t *wr = reinterpret_cast<const f32x4_t *>(sW) + (ent & 255u) * (DW_STRIDE / 4) + 8 * c;
                 const f32x2_t d2 = {d, d};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const f32x4_t w = wr[j];
-                    pk_fma_acc(a[2 * j], d2, w.lo);
-                    pk_fma_acc(a[2 * j + 1], d2, w.hi);
-                }
+                delta_apply_32(a, d2, sW_lds + (ent & 255u) * (DW_STRIDE * 4) + 128u * (uint32_t)c);
+                ent = nent;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

@@ -782,6 +782,9 @@ def test_incremental_value_net_equals_dense_chain(bg, O, weights):
         assert np.abs(va[moved] - vb[moved]).max() < 2e-6
         vc = _np(c.last_choice()["value"])
         assert np.abs(va[moved] - vc[moved]).max() < 1e-6      # bf16 x 3 root term == f32 MFMA root term (fp32 rounding)
+        print("burn %d: max |incremental - dense| = %.3g, max |bf16x3 root - f32 root| = %.3g, same move on %.4f of lanes"
+              % (burn, np.abs(va[moved] - vb[moved]).max(), np.abs(va[moved] - vc[moved]).max(),
+                 (_np(a.states()) == _np(b.states())).all(axis=1).mean()))
         assert ((_np(c.states()) == _np(a.states())).all(axis=1)).mean() > 0.995
         sa, sb = _np(a.states()), _np(b.states())
         same = (sa == sb).all(axis=1)
