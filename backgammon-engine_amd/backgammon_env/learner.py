@@ -163,9 +163,10 @@ class DeviceTDLambdaLearner:
         self._capi.check(self._lib.bgamd_td_times(self._h, C.byref(ms), C.byref(n), C.byref(gs)), "td_times")
         return ms.value, n.value, gs.value
 
-    def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0):
+    def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0, split_apply: bool = False):
         """rows: int32 [T, n, 8] trajectory log (VecGame.record_trajectory / play_round), lengths: int [n] logged
-        turns per lane (0 = do not replay), p1_won: bool [n].  Returns (Σ δ², number of (game, step) updates)."""
+        turns per lane (0 = do not replay), p1_won: bool [n].  Returns (Σ δ², number of (game, step) updates).
+        split_apply: take the step / all-reduce / apply route of the distributed replay even on one rank."""
         C, lib, chk = self._C, self._lib, self._capi.check
         rows = rows.contiguous()
         T, n = int(rows.shape[0]), int(rows.shape[1])
@@ -188,19 +189,21 @@ class DeviceTDLambdaLearner:
         alpha = float(self.learning_rate) * float(batch_scale)
         lam = float(self.lambda_decay)
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        if not distributed:
+        if not distributed and not split_apply:
             arr = (C.c_int64 * max(n_steps, 1))(*n_active)
             chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
         else:
             ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
-            dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)      # every rank issues the same collectives
+            if distributed:
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)  # every rank issues the same collectives
             upd = torch.zeros(25601, dtype=torch.float32, device=self.device)
             for t in range(int(ns.item())):
                 if t < n_steps:
                     chk(lib.bgamd_td_step(self._h, t, n_active[t], alpha, lam, self._p(upd), self._s()), "td_step")
                 else:
                     upd.zero_()
-                dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)  # the ONE collective per training step
+                if distributed:
+                    dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)  # the ONE collective per training step
                 chk(lib.bgamd_td_apply(self._h, self._p(upd), self._s()), "td_apply")
         sq, cnt = C.c_double(), C.c_int64()
         chk(lib.bgamd_td_stats(self._h, C.byref(sq), C.byref(cnt)), "td_stats")

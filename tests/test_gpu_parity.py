@@ -752,6 +752,10 @@ def test_device_learner_round_matches_host_closed_form(bg, O, weights):
     Ld.set_weights(weights)
     Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.25)
     assert np.array_equal(_np(Ld.theta), out[0])
+    # the distributed route (bgamd_td_step hands the update out, the caller all-reduces, bgamd_td_apply) on one rank
+    Ld.set_weights(weights)
+    sq_s, cnt_s = Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.25, split_apply=True)
+    assert cnt_s == cnt_c and np.array_equal(_np(Ld.theta), out[0])
 
 
 def test_incremental_value_net_equals_dense_chain(bg, O, weights):
