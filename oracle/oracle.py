@@ -224,3 +224,42 @@ def lane_initial(seed, lane_id, stride):
     lane = Lane()
     lib().bgo_lane_reset(C.byref(lane), seed, lane_id, stride)
     return lane
+
+
+def td_lambda_lockstep(weights, X, lengths, p1_won, alpha: float, lam: float, batch_scale: float = 1.0):
+    """TD(lambda) restated from the reference learner, in float64 numpy, for the learner parity tests.
+
+    One game: `apply_td_updates` (pysrc/TD(λ) model/train.py:124-172) step for step -- for t = 0..T-2
+    delta = V(s_{t+1}) - V(s_t) (train.py:136-141), traces e <- lam e + grad V(s_t) (train.py:150-158, reset per game
+    train.py:539-540), theta += alpha delta e (train.py:159-161); terminal step delta = z - V(s_{T-1}) with z = 1 if
+    PLAYER1 won (train.py:165-170).  grad V is written in closed form (sigmoid(fc2(sigmoid(fc1 x))), model.py:63-67).
+    Several games: step t of every game with a turn t is taken from the SAME weights and the updates are summed (the
+    documented mini-batch deviation of the device learner); batch_scale multiplies alpha.
+    X: [T, G, 198] encodings of the pre-move states, lengths[G] logged turns (0 = game not replayed), p1_won[G].
+    Returns (weights_after float64[25601], sum of squared TD errors, number of (game, step) updates)."""
+    th = np.asarray(weights, dtype=np.float64).copy()
+    X = np.asarray(X, dtype=np.float64)
+    T, G = X.shape[0], X.shape[1]
+    lengths = np.asarray(lengths).astype(np.int64)
+    z = np.asarray(p1_won).astype(np.float64)
+    e = np.zeros((G, N_PARAMS), dtype=np.float64)
+    o1, o2, o3 = N_HID * N_IN, N_HID * N_IN + N_HID, N_HID * N_IN + 2 * N_HID
+    sq, cnt = 0.0, 0
+
+    def fwd(x):
+        h = 1.0 / (1.0 + np.exp(-(x @ th[:o1].reshape(N_HID, N_IN).T + th[o1:o2])))
+        return 1.0 / (1.0 + np.exp(-(h @ th[o2:o3] + th[o3]))), h
+
+    for t in range(int(lengths.max()) if G else 0):
+        act = lengths > t
+        v, h = fwd(X[t])
+        vn = fwd(X[t + 1])[0] if t + 1 < T else np.zeros(G)
+        delta = np.where(lengths == t + 1, z - v, vn - v) * act
+        g = v * (1.0 - v) * act
+        db1 = (g[:, None] * th[o2:o3][None, :]) * h * (1.0 - h)
+        grad = np.concatenate([(db1[:, :, None] * X[t][:, None, :]).reshape(G, o1), db1, g[:, None] * h, g[:, None]], axis=1)
+        e = lam * e + grad
+        th = th + (alpha * batch_scale * delta) @ e
+        sq += float((delta ** 2).sum())
+        cnt += int(act.sum())
+    return th, sq, cnt

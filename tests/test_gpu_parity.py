@@ -737,6 +737,9 @@ def test_device_learner_round_matches_host_closed_form(bg, O, weights):
     Xr = env.encode_rows(rows).cpu().double()
     Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.9, dtype=torch.float64)
     sq_c, cnt_c = Lc.replay(Xr, lengths.cpu(), p1_won.cpu(), batch_scale=0.25)
+    # ... and the oracle's independent numpy restatement of the reference learner says the same
+    th_o, sq_o, cnt_o = O.td_lambda_lockstep(weights, Xr.numpy(), ln, _np(p1_won), 0.1, 0.9, batch_scale=0.25)
+    assert cnt_o == cnt_c and np.abs(th_o - Lc.theta.numpy()).max() < 1e-10
     out = []
     for rep in range(2):
         Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.9)

@@ -54,3 +54,27 @@ def test_checkpoint_interop_state_dict_roundtrip(tmp_path, weights):
     m = TDLGammonModel()
     m.load_state_dict(sd)
     assert np.array_equal(m._w, weights) and np.array_equal(flatten_state_dict(m.state_dict()), weights)
+
+
+def test_oracle_td_restatement_matches_reference_fixture_and_host_learner(golden_dir, weights):
+    """The numpy float64 restatement in oracle/ (the checker of the device learner) reproduces the reference's own
+    update (fixture G6) and agrees with the host-side closed form on a ragged multi-game round."""
+    from backgammon_env.learner import TDLambdaLearner
+    g = np.load(os.path.join(golden_dir, "g6_td_lambda.npz"))
+    st, turn = g["states"].astype(np.int32), g["turn"]
+    X = np.stack([O.encode(st[i:i + 1], int(turn[i]))[0] for i in range(len(st))])[:, None, :]
+    alpha, lam = g["alpha_lambda"]
+    th, sq, cnt = O.td_lambda_lockstep(weights, X, [len(st)], [int(g["winner"][0]) == 0], alpha, lam)
+    assert cnt == len(st) and np.abs(th - g["w_after"]).max() < 2e-6
+    lanes = [O.lane_run(9, lane, 8, 30 + 3 * lane, 0)[0] for lane in range(5)]
+    lengths = [30, 33, 0, 12, 1]
+    T = 34
+    Xm = np.zeros((T, 5, 198), dtype=np.float32)
+    for k, l in enumerate(lanes):
+        for t in range(min(T, len(l))):
+            Xm[t, k] = O.encode(l[t:t + 1, :28], int(l[t, 28]))[0]
+    tho, sqo, cnto = O.td_lambda_lockstep(weights, Xm, lengths, [1, 0, 1, 0, 1], 0.1, 0.9, batch_scale=0.5)
+    L = TDLambdaLearner(weights, alpha=0.1, lam=0.9, dtype=torch.float64)
+    sql, cntl = L.replay(torch.from_numpy(Xm).double(), lengths, [1, 0, 1, 0, 1], batch_scale=0.5)
+    assert cntl == cnto == sum(lengths)
+    assert np.abs(L.theta.numpy() - tho).max() < 1e-12 and abs(sql - sqo) < 1e-9
