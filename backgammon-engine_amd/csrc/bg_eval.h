@@ -260,12 +260,12 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
 // ================================ incremental fp32 evaluator ======================================
 // Every afterstate of a turn differs from the turn's root position in the few points its <= 4 moves touched, and
 // the encoder (model.py:111-144) is a thermometer code: a count that changes by one flips exactly one feature.
-// So with  a_root = W1 x_root + b1  (one dense pass per GAME, eval_rows_f32_kernel<true> on the MFMA pipe),
+// So with  a_root = W1 x_root + b1  (one dense pass per GAME on the MFMA pipe: root_hidden_bf16x3_kernel below),
 //     a_row = a_root + Σ_{changed features f} Δx_f · W1[:, f]        (typically 4-8 columns instead of 198)
 // in fp32 FMAs; hidden sigmoid, W2 dot, output sigmoid and the per-game arg-max are as in the dense kernel.
 // Lane = row, 32 hidden units at a time in registers, W1^T in LDS (132-float row stride), each lane's (row, Δ) list in LDS.
 // The sum is the same real number as the dense chain with a different association: values agree to ~1e-7.
-constexpr int DELTA_THREADS = 1024;                     // 4 waves per SIMD: the kernel lives on latency hiding
+constexpr int DELTA_THREADS = 1024;                     // 16 waves per CU, one workgroup per CU (LDS: W1^T + the lists)
 constexpr int DW_STRIDE = 132;                          // floats per feature row of W1^T in LDS
 // Row of feature f in the LDS table: 9 * point + (4 * side + level) for the board features, 216.. for the tail.  The
 // LDS bank class of a 16-byte read is (row + chunk) mod 8; candidates of one game mostly differ in WHICH point a
@@ -293,16 +293,10 @@ inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[DW_RO
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-// acc += d * w on both halves, IN PLACE (left to itself the compiler renames the 128 loop-carried accumulators
-// every iteration and copies them back)
-__device__ __forceinline__ void pk_fma_acc(f32x2_t &acc, f32x2_t d, f32x2_t w)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(d), "v"(w));
-}
-
 // One list entry for 32 hidden units: a[0..15] += d * W1^T[row][32c .. 32c+31], the 8 ds_read_b128 software-pipelined by
-// hand (four reads in flight, FMAs issued as each lands).  The compiler, short of registers at 4 waves per SIMD,
-// serialised the reads with full lgkmcnt(0) waits; the temporaries here are the fixed registers v[108:127].
+// hand (four reads in flight, FMAs issued as each lands) and the packed FMAs pinned IN PLACE.  Left to itself the
+// compiler renamed the loop-carried accumulators every iteration and copied them back, and, short of registers at 4
+// waves per SIMD, serialised the reads with full lgkmcnt(0) waits; the temporaries are the fixed registers v[108:127].
 __device__ __forceinline__ void delta_apply_32(f32x2_t (&a)[16], f32x2_t d2, uint32_t lds_addr)
 {
     asm volatile(
