@@ -801,3 +801,30 @@ def test_incremental_value_net_equals_dense_chain(bg, O, weights):
         _check_greedy_step(O, weights, pre, pt, dice, sa, lanes)
         _check_greedy_step(O, weights, pre, pt, dice, sb, lanes)
         assert a.stats()["error_flags"] == 0
+
+
+def test_step_is_graph_capturable(bg, weights):
+    """The greedy step is pure stream-ordered work (no host synchronisation, no host-side state): it can be captured in
+    a HIP graph through torch and replayed; the replayed games equal the eagerly stepped ones bit for bit."""
+    n, per_graph, replays = 2048, 4, 6
+    a, b = bg.VecGame(n, seed=99), bg.VecGame(n, seed=99)
+    a.load_weights(weights); b.load_weights(weights)
+    b.step_greedy(epsilon=0.1)                       # warm-up outside capture (lazy module load, event pools)
+    a.step_greedy(epsilon=0.1)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                b.step_greedy(epsilon=0.1)
+    # capture records, it does not execute: a and b are still in step
+    for _ in range(replays):
+        g.replay()
+    for _ in range(per_graph * replays):
+        a.step_greedy(epsilon=0.1)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(a.states()), _np(b.states())) and np.array_equal(_np(a.turns()), _np(b.turns()))
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert all(sa[k] == sb[k] for k in ("steps", "games_finished", "p1_wins"))
