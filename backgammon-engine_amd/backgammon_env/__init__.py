@@ -239,6 +239,18 @@ class VecGame:
                     "last_choice")
         return {"chosen": ch, "count": cnt, "seq": sq, "seq_len": ln, "value": val}
 
+    def unique_rows_info(self):
+        """Diagnostics: (game, key | turn << 31) of every afterstate the value net evaluated in the last greedy step
+        -> int64 [U, 2] device tensor (columns game, key)."""
+        cap = 1 << 16
+        while True:
+            buf = self._buf((cap, 2), torch.int32)
+            n = _capi.check(self._lib.bgamd_env_unique_rows_info(self._h, _ptr(buf), cap, _stream()), "unique_rows_info")
+            if n <= cap:
+                torch.cuda.current_stream().synchronize()
+                return buf[:n].to(torch.int64) & 0xFFFFFFFF
+            cap = int(n)
+
     def stats(self):
         out = (C.c_uint64 * 10)()
         _capi.check(self._lib.bgamd_env_stats(self._h, out), "stats")

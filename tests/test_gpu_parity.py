@@ -828,3 +828,51 @@ def test_step_is_graph_capturable(bg, weights):
     sa, sb = a.stats(), b.stats()
     assert sa["error_flags"] == 0 and sb["error_flags"] == 0
     assert all(sa[k] == sb[k] for k in ("steps", "games_finished", "p1_wins"))
+
+
+def _replay_key(O, pre28, turn, d1, d2, key):
+    """Afterstate of the move sequence a staged row's key describes (pass | o0..o3 | len), through the oracle."""
+    ln, pas = key & 7, (key >> 23) & 1
+    dA, dB = (d2, d1) if pas else (d1, d2)
+    s = O.State.from28(pre28, turn)
+    for k in range(ln):
+        o, die = (key >> (18 - 5 * k)) & 31, (dB if k & 1 else dA)
+        dest = [b for a, b in O.legal_moves(s, turn, die) if a == o]
+        assert dest, ("key names an illegal move", key, k, o, die)
+        ok, msg = O.try_move(s, turn, die, o, dest[0])
+        assert ok, msg
+    return tuple(int(v) for v in s.to28())
+
+
+def test_staged_rows_cover_every_distinct_afterstate(bg, O, weights):
+    """What the value net is handed in a greedy step: every key replays (through the oracle's tryMove) to a legal
+    afterstate, and the set of those afterstates is EXACTLY the set of distinct afterstates of the reference-order
+    enumeration -- the de-duplication drops copies, never a position."""
+    n = 1024
+    env = bg.VecGame(n, seed=2024)
+    env.load_weights(weights)
+    rows_total = distinct_total = 0
+    for ply in range(36):
+        pre, pt = _np(env.states()), _np(env.turns())
+        live = (_np(env.flags()) & 4) == 0
+        env.step_greedy(auto_reset=False)
+        if ply % 5:
+            continue
+        dice = _np(env.dice())
+        info = _np(env.unique_rows_info())
+        by_game = {}
+        for g, k in info:
+            by_game.setdefault(int(g), []).append(int(k))
+        for lane in range(0, n, 3):
+            if not live[lane]:
+                assert lane not in by_game
+                continue
+            turn, d1, d2 = int(pt[lane]), int(dice[lane, 0]), int(dice[lane, 1])
+            _, _, cand = O.evaluate_turn_sequences(O.State.from28(pre[lane], turn), turn, d1, d2)
+            want = {tuple(int(v) for v in c) for c in cand}
+            keys = by_game.get(lane, [])
+            assert all((k >> 31) == turn for k in keys)
+            got = {_replay_key(O, pre[lane], turn, d1, d2, k & 0x7FFFFFFF) for k in keys}
+            assert got == want, (ply, lane, len(got), len(want))
+            rows_total += len(keys); distinct_total += len(want)
+    assert distinct_total > 20000 and rows_total < 1.25 * distinct_total
