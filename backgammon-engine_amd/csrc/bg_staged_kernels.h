@@ -164,7 +164,27 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
             if (valid) {
                 die = (s.len & 1) ? s.dB : s.dA;
                 if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
-                cnt = m0 ? (uint32_t)__popc(m0) : 1u;
+                bool pruned_all = false;
+                if (MODE == MODE_LEAF && !s.dbl && s.len == 1 && key_pass(nd.key) && m0) {
+                    // Non-doubles, second die order: this node is "x with d2", its successors are "then y with d1".
+                    // If y was a legal FIRST move with d1 and x is then legal with d2, the first die order already
+                    // produced (y, x) -- the same two checker moves, the same landing points, hence the same
+                    // afterstate under a smaller key.  Such successors are not generated at all (about a third of
+                    // the staged leaves); whatever this test does not prove equal still goes through the hash.
+                    Side rown, ropp;
+                    split_sides(pl_next, s.pl, rown, ropp);
+                    const int x = key_origin(nd.key, 0);
+                    uint32_t cand = m0 & legal_origins(rown, ropp, s.pl, s.dB), dup = 0;
+                    while (cand) {
+                        const int y = __ffs(cand) - 1; cand &= cand - 1;
+                        Side a = rown, b = ropp;
+                        apply_move(a, b, s.pl, y, s.dB);
+                        if ((legal_origins(a, b, s.pl, s.dA) >> x) & 1u) dup |= 1u << y;
+                    }
+                    m0 &= ~dup;
+                    pruned_all = m0 == 0;
+                }
+                cnt = m0 ? (uint32_t)__popc(m0) : (pruned_all ? 0u : 1u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s_par_plane[k][threadIdx.x] = s.own.b[k]; s_par_plane[4 + k][threadIdx.x] = s.opp.b[k]; }
                 s_par_mask[threadIdx.x] = m0;
