@@ -351,14 +351,22 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     uint16_t *sList = reinterpret_cast<uint16_t *>(sW2 + N_HID) + (threadIdx.x >> 6) * (DELTA_MAX * 64);
     for (int i = threadIdx.x; i < DELTA_W_FLOATS / 4; i += DELTA_THREADS) sW[i] = wt[i];
     if (threadIdx.x < N_HID) sW2[threadIdx.x] = w2[threadIdx.x];
+    __shared__ unsigned int s_ticket;                    // tiles of this workgroup's range are handed out on demand
+    if (threadIdx.x == 0) s_ticket = 0;
     __syncthreads();
 
     const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 63) >> 6;
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * (DELTA_THREADS / 64) + (threadIdx.x >> 6);
-    const long long n_waves = (long long)gridDim.x * (DELTA_THREADS / 64);
+    // A tile's cost follows its longest delta list (a doubles turn costs twice a plain one), so the 64-row tiles of a
+    // workgroup's contiguous range go to whichever wave is free (LDS ticket) instead of a fixed stride per wave
+    const long long t_lo = n_tiles * blockIdx.x / gridDim.x, t_hi = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    auto grab = [&]() -> long long {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(&s_ticket, 1u);
+        return t_lo + (long long)__builtin_amdgcn_readfirstlane(t);
+    };
     const float b2 = *b2p;
     constexpr float NL2E = -1.44269504088896340736f;
     uint32_t n_delta = 0;
@@ -366,8 +374,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     // software pipeline: the next tile's row + info are in flight while this tile is computed
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
     uint2 nxi = make_uint2(0u, 0u);
-    if (wave < n_tiles && wave * 64 + lane < n_rows) {
-        const long long r0 = wave * 64 + lane;
+    long long tile = grab();
+    if (tile < t_hi && tile * 64 + lane < n_rows) {
+        const long long r0 = tile * 64 + lane;
         nx0 = rows[2 * r0]; nx1 = rows[2 * r0 + 1]; nxi = info[r0];
     }
     // ... and so are its game's root row and the first 32 hidden units of the root term (issued during the LAST chunk
@@ -379,7 +388,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) nxt[j] = ah0[j];
     }
-    for (long long tile = wave; tile < n_tiles; tile += n_waves) {
+    while (tile < t_hi) {
+        const long long next_tile = grab();
         const long long row = tile * 64 + lane;
         const bool valid = row < n_rows;
         const uint2 inf = nxi;                             // (0, 0) for a padding lane: game 0, harmless
@@ -389,9 +399,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         const uint32_t q[8] = {valid ? r0.x & ~TURN_BIT : 0u, valid ? r0.y : 0u, valid ? r0.z : 0u, valid ? r0.w : 0u,
                                valid ? r1.x : 0u, valid ? r1.y : 0u, valid ? r1.z : 0u, valid ? r1.w : 0u};
         {
-            const long long nrow = (tile + n_waves) * 64 + lane;
+            const long long nrow = next_tile * 64 + lane;
             nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0); nxi = make_uint2(0u, 0u);
-            if (nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
+            if (next_tile < t_hi && nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
         }
 
         // ---- this lane's (feature, Δ) list: 16-bit entry = feature | (2Δ as int8) << 8; TYPE 0: Δ = m, 1: Δ = m/2,
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
             bits = (inf.y >> 31) ? ~bits : bits;
             atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
         }
+        tile = next_tile;
     }
     __shared__ unsigned int s_nd;
     if (threadIdx.x == 0) s_nd = 0;
