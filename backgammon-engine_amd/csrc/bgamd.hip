@@ -547,6 +547,9 @@ struct bgamd_env {
     uint2 *d_lut16 = nullptr;              // count -> 4 f16 features
     bool has_weights[2] = {false, false};
     int n_cu = 256;
+    hipStream_t side = nullptr;            // second stream: the root pass of the value net runs beside the doubles plies
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
+    bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
@@ -644,6 +647,14 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
+    env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr;
+    if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess) {
+        g_hip_err = "side stream / events";
+        bgamd_env_destroy(env);
+        return BGAMD_E_HIP;
+    }
     *out = env;
     return BGAMD_OK;
 }
@@ -726,6 +737,9 @@ int bgamd_env_destroy(bgamd_env *env)
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
+    if (env->ev_fork) hipEventDestroy(env->ev_fork);
+    if (env->ev_join) hipEventDestroy(env->ev_join);
+    if (env->side) hipStreamDestroy(env->side);
     delete env;
     return BGAMD_OK;
 }
@@ -955,23 +969,25 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         const long long lim = (long long)env->n_cu * 2;
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
     };
+    const bool incremental = precision == BGAMD_F32;
+    const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
     {
         KTimer t(env, s, 4);
         hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
-        hipLaunchKernelGGL(stage2_kernel<MODE_PLY2>, sgrid(n * 15, MODE_PLY2), dim3(STAGE_THREADS), 0, s, env->v, sv);
-        hipLaunchKernelGGL(stage2_kernel<MODE_PLY3>, sgrid(n * 225, MODE_PLY3), dim3(STAGE_THREADS), 0, s, env->v, sv);
     }
-    {
-        KTimer t(env, s, 5);
-        hipLaunchKernelGGL(stage2_kernel<MODE_LEAF>, sgrid2(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
-    }
-    if (precision == BGAMD_F32) {
-        // incremental fp32 evaluator: one dense pass per GAME for the root term, then a few W1 columns per afterstate
-        const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    if (incremental) {
+        // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows roots_kernel just wrote.
+        // It runs on the env's second stream beside the doubles plies -- two small latency-bound launches that leave
+        // most of the chip idle -- and is joined before the incremental kernel.
+        hipStream_t s2 = env->overlap ? env->side : s;
+        if (env->overlap) {
+            HIPCHK(hipEventRecord(env->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(s2, env->ev_fork, 0));
+        }
         {
-            KTimer t(env, s, 6);
+            KTimer t(env, s2, 6);
             if (env->root_f32_mfma)
-                hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s,
+                hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
                                    (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
                                    (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
                                    (unsigned long long *)nullptr, (unsigned long long *)nullptr);
@@ -979,17 +995,28 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
                 long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
                 if (blocks > env->n_cu) blocks = env->n_cu;
                 hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
-                                   ROOT3_LDS_TOTAL, s, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
+                                   ROOT3_LDS_TOTAL, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
                                    (const uint2 *)env->d_lut, b1, sv.root_hidden);
             }
         }
-        {
-            KTimer t(env, s, 1);
-            hipLaunchKernelGGL(eval_rows_delta_kernel, dim3(env->n_cu), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
-                               (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], 0ll, &env->v.counters[C_ROWS_EVAL],
-                               (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
-                               env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
-        }
+        if (env->overlap) HIPCHK(hipEventRecord(env->ev_join, s2));
+    }
+    {
+        KTimer t(env, s, 4);
+        hipLaunchKernelGGL(stage2_kernel<MODE_PLY2>, sgrid(n * 15, MODE_PLY2), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(stage2_kernel<MODE_PLY3>, sgrid(n * 225, MODE_PLY3), dim3(STAGE_THREADS), 0, s, env->v, sv);
+    }
+    {
+        KTimer t(env, s, 5);
+        hipLaunchKernelGGL(stage2_kernel<MODE_LEAF>, sgrid2(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
+    }
+    if (incremental) {
+        if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
+        KTimer t(env, s, 1);
+        hipLaunchKernelGGL(eval_rows_delta_kernel, dim3(env->n_cu), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
+                           (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], 0ll, &env->v.counters[C_ROWS_EVAL],
+                           (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
+                           env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
     } else {
         rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
         if (rc) return rc;

@@ -225,7 +225,8 @@ def main():
     }
     if kt:
         nl = max(kt["eval"]["launches"], 1)
-        per = {k: (v["ms"] / v["launches"] if v["launches"] else 0.0) for k, v in kt.items()}
+        # per-step GPU time of each kernel group (a group may be bracketed more than once per step)
+        per = {k: (v["ms"] / (nl if k == "eval" else max(kt2["eval"]["launches"], 1)) if v["launches"] else 0.0) for k, v in kt.items()}
         rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
         fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
         u_l = steps_l * u_step                                 # distinct afterstates per launch (sampled U per step)
