@@ -120,6 +120,10 @@ template <int MODE>
 __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, StagedView sv)
 {
     constexpr int NT = STAGE_THREADS;
+    // nodes per block iteration.  The doubles plies have few nodes (tens of thousands per launch) and live on the LDS
+    // latency of the hash phase: a quarter / half of the threads take a node, so a block stages ~1-2 successors per
+    // lane instead of ~5 in sequence and the nodes spread over all CUs instead of a fifth of them
+    constexpr int NPB = MODE == MODE_PLY2 ? NT / 4 : (MODE == MODE_PLY3 ? NT / 2 : NT);
     constexpr int CAP = stage_cap(MODE);
     constexpr int TSLOTS = 2 * CAP;
     constexpr int NW = NT / 64;
@@ -146,13 +150,13 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
     Node nd_next{0u, 0u};
     uint32_t pl_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}, meta_next = 0;
     {
-        const unsigned long long n0 = (unsigned long long)blockIdx.x * NT + threadIdx.x;
-        if (n0 < n_in) { nd_next = in[n0]; load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
+        const unsigned long long n0 = (unsigned long long)blockIdx.x * NPB + threadIdx.x;
+        if (threadIdx.x < NPB && n0 < n_in) { nd_next = in[n0]; load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
     }
-    for (unsigned long long blk = blockIdx.x; blk * NT < n_in; blk += gridDim.x) {
-        const unsigned long long ni = blk * NT + threadIdx.x;
-        const bool valid = ni < n_in;
-        const unsigned long long ni_next = (blk + gridDim.x) * NT + threadIdx.x;
+    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+        const unsigned long long ni = blk * NPB + threadIdx.x;
+        const bool valid = threadIdx.x < NPB && ni < n_in;
+        const unsigned long long ni_next = threadIdx.x < NPB ? (blk + gridDim.x) * NPB + threadIdx.x : ~0ull;
         uint32_t cnt = 0;
         {
             const Node nd = nd_next;
