@@ -87,7 +87,7 @@ inline void relayout_w1_f32(const float *w1 /*[128][198]*/, float *wl /*[99][64]
                 wl[(s * 64 + l) * 4 + c] = w1[(32 * c + (l & 31)) * N_IN + 2 * s + (l >> 5)];
 }
 
-// rows: 2 x uint4 per candidate.  n_rows_ptr: device counter (rows emitted this step), or null -> n_rows_imm.
+// rows: 2 x uint4 per candidate.  n_rows_ptr: device counter (rows emitted this step) capped by n_rows_imm, or null -> n_rows_imm.
 constexpr int EVAL_RED_STRIDE = 33;                                   // floats per column in the reduction scratch
 constexpr int EVAL_RED_FLOATS = 32 * EVAL_RED_STRIDE;                 // per wave
 constexpr int EVAL_LDS_TOTAL = EVAL_LDS_BYTES + (EVAL_THREADS / 64) * EVAL_RED_FLOATS * 4;
@@ -106,7 +106,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
     for (int i = threadIdx.x; i < K_STEPS * 64; i += EVAL_THREADS) sW[i] = wl[i];
     __syncthreads();
 
-    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    // device counter (clamped to the arena capacity passed in n_rows_imm: an overflowing step is flagged, never read
+    // past the arena) or the immediate count
+    long long n_rows = n_rows_imm;
+    if (n_rows_ptr) { const long long c = (long long)*n_rows_ptr; n_rows = c < n_rows_imm ? c : n_rows_imm; }
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 31) >> 5;
     const int lane = threadIdx.x & 63;
@@ -355,7 +358,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     if (threadIdx.x == 0) s_ticket = 0;
     __syncthreads();
 
-    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    // device counter (clamped to the arena capacity passed in n_rows_imm: an overflowing step is flagged, never read
+    // past the arena) or the immediate count
+    long long n_rows = n_rows_imm;
+    if (n_rows_ptr) { const long long c = (long long)*n_rows_ptr; n_rows = c < n_rows_imm ? c : n_rows_imm; }
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 63) >> 6;
     const int lane = threadIdx.x & 63;
@@ -568,7 +574,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_bf16_kernel(
     if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
 
-    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    // device counter (clamped to the arena capacity passed in n_rows_imm: an overflowing step is flagged, never read
+    // past the arena) or the immediate count
+    long long n_rows = n_rows_imm;
+    if (n_rows_ptr) { const long long c = (long long)*n_rows_ptr; n_rows = c < n_rows_imm ? c : n_rows_imm; }
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 31) >> 5;
     const int lane = threadIdx.x & 63;
@@ -831,7 +840,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f16x2_kernel(
     if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
 
-    const long long n_rows = n_rows_ptr ? (long long)*n_rows_ptr : n_rows_imm;
+    // device counter (clamped to the arena capacity passed in n_rows_imm: an overflowing step is flagged, never read
+    // past the arena) or the immediate count
+    long long n_rows = n_rows_imm;
+    if (n_rows_ptr) { const long long c = (long long)*n_rows_ptr; n_rows = c < n_rows_imm ? c : n_rows_imm; }
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 31) >> 5;
     const int lane = threadIdx.x & 63;

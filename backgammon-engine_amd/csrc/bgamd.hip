@@ -707,6 +707,9 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.u_rows, (size_t)cap * 32));
         HIPCHK(hipMalloc(&sv.u_info, (size_t)cap * sizeof(uint2)));
+        // an overflowing step (flagged, raised by stats) leaves holes in the arena: they must name a valid game
+        HIPCHK(hipMemset(sv.u_rows, 0, (size_t)cap * 32));
+        HIPCHK(hipMemset(sv.u_info, 0, (size_t)cap * sizeof(uint2)));
         HIPCHK(hipMalloc(&sv.best, n * 8));
         HIPCHK(hipMalloc(&sv.root_rows, n * 32));
         HIPCHK(hipMalloc(&sv.root_hidden, n * N_HID * 4));
@@ -1014,11 +1017,11 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
         if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_delta_kernel, dim3(env->n_cu), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
-                           (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], 0ll, &env->v.counters[C_ROWS_EVAL],
+                           (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                            (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
                            env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
     } else {
-        rc = launch_eval(env, slot, precision, &sv.tops[T_U], 0, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
+        rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
         if (rc) return rc;
     }
     ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};

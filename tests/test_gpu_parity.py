@@ -649,6 +649,11 @@ def test_errors_are_loud(bg, weights):
     small.roll()
     with pytest.raises(bg.BgamdError):
         small.enumerate()                                     # BGAMD_E_ARENA
+    tiny = bg.VecGame(70000, arena_rows=65536)                # the greedy step overflows its afterstate arena too:
+    tiny.load_weights(weights)                                #   flagged, the value net stays inside the arena
+    tiny.step_greedy()
+    with pytest.raises(bg.BgamdError):
+        tiny.stats()
     g = bg.Game(0)
     with pytest.raises(ValueError):
         g.setGameBoard([0] * 25)
