@@ -56,8 +56,11 @@ __global__ void td_gather_kernel(TdView v)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n_games) return;
-    const int lane = v.order[i];
-    v.gmeta[i] = make_int4(lane, v.length[lane], v.p1_won[lane] ? 1 : 0, 0);
+    int lane = v.order[i];                               // caller data: kept inside the log whatever it says
+    lane = lane < 0 ? 0 : (lane >= v.n_lanes ? (int)v.n_lanes - 1 : lane);
+    int len = v.length[lane];
+    len = len < 0 ? 0 : (len > v.T ? (int)v.T : len);
+    v.gmeta[i] = make_int4(lane, len, v.p1_won[lane] ? 1 : 0, 0);
     v.sq[i] = 0.0;
 }
 
