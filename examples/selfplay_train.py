@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rehearsal of configs 4/5 on ONE GPU: batched self-play with the turn log, lock-step TD(λ)
-replay (HIP learner kernels, bgamd_td_*; --host-learner = the PyTorch closed form), weights back into the env; win rate against a uniformly random mover before and after.
+replay (HIP learner kernels, bgamd_td_*; --host-learner = the PyTorch closed form), weights back into the env;
+win rate against a uniformly random mover before and after, and against the reference's 100k-episode checkpoint.
 Not the reference's training CLI (out of scope) -- a 60-line demonstration that the pieces compose.
 
     python examples/selfplay_train.py --games 512 --rounds 120
@@ -58,7 +59,11 @@ def main():
         if r % 20 == 19:
             print(f"round {r + 1}: {(r + 1) * a.games} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
                   f"{turns / (time.time() - t0):.0f} turns/s", flush=True)
-    print("after: vs random", head_to_head(arena, L.theta.cpu().numpy(), None), flush=True)
+    w_after = L.theta.cpu().numpy()
+    print("after: vs random", head_to_head(arena, w_after, None), flush=True)
+    ref = os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32")       # the reference's own 100k-episode checkpoint
+    if os.path.exists(ref):
+        print("after: vs tdgammonNEW100k", head_to_head(arena, w_after, np.fromfile(ref, dtype=np.float32)), flush=True)
 
 
 if __name__ == "__main__":
