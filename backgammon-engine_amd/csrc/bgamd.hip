@@ -931,19 +931,25 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
     if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2 && precision != BGAMD_F32_DENSE)
         return BGAMD_E_INVALID;
     const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    // every workgroup first stages W1 in LDS: no more workgroups than the rows can use (a greedy step averages ~18
+    // rows per game; more than the estimate only means more tiles per wave)
+    const long long est_rows = n_rows_ptr ? env->v.n * 24 : n_rows_imm;
+    long long eb = (est_rows + (EVAL_THREADS / 64) * 32 - 1) / ((EVAL_THREADS / 64) * 32);
+    eb = eb < 1 ? 1 : (eb > env->n_cu ? env->n_cu : eb);
+    const dim3 egrid((unsigned)eb);
     if (precision == BGAMD_F16X2) {
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_f16x2_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16X2_LDS_TOTAL, s, rows, n_rows_ptr,
+        hipLaunchKernelGGL(eval_rows_f16x2_kernel, egrid, dim3(EVAL_THREADS), EVAL16X2_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const uint4 *)env->d_wlx2[slot], (const uint2 *)env->d_lut16, b1, w2, b2, values, info, best);
     } else if (precision == BGAMD_BF16) {
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_bf16_kernel, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL16_LDS_TOTAL, s, rows, n_rows_ptr,
+        hipLaunchKernelGGL(eval_rows_bf16_kernel, egrid, dim3(EVAL_THREADS), EVAL16_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const uint4 *)env->d_wl16[slot], (const uint2 *)env->d_lut, b1, w2, b2, values, info, best);
     } else {
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_f32_kernel<false>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
+        hipLaunchKernelGGL(eval_rows_f32_kernel<false>, egrid, dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const float4 *)env->d_wl[slot], b1, w2, b2, values, info, best,
                            n_rows_ptr ? &env->v.counters[C_KSTEPS] : (unsigned long long *)nullptr);
@@ -1016,7 +1022,10 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     if (incremental) {
         if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
         KTimer t(env, s, 1);
-        hipLaunchKernelGGL(eval_rows_delta_kernel, dim3(env->n_cu), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
+        // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
+        long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
+        dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
+        hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
                            (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                            (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
                            env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
