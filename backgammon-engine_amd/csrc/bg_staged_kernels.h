@@ -123,7 +123,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
     // nodes per block iteration.  The doubles plies have few nodes (tens of thousands per launch) and live on the LDS
     // latency of the hash phase: a quarter / half of the threads take a node, so a block stages ~1-2 successors per
     // lane instead of ~5 in sequence and the nodes spread over all CUs instead of a fifth of them
-    constexpr int NPB = MODE == MODE_PLY2 ? NT / 4 : (MODE == MODE_PLY3 ? NT / 2 : NT);
+    constexpr int NPB_MAX = MODE == MODE_PLY2 ? NT / 4 : (MODE == MODE_PLY3 ? NT / 2 : NT);
     constexpr int CAP = stage_cap(MODE);
     constexpr int TSLOTS = 2 * CAP;
     constexpr int NW = NT / 64;
@@ -139,6 +139,11 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
     const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
     unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
     if (n_in > cap_in) n_in = cap_in;
+    // ... and when the launch has fewer nodes than that per workgroup (small envs), they are spread over the whole
+    // grid, 64 at least (a game's nodes stay together for the de-duplication): one short round instead of several
+    unsigned long long NPB = (n_in + gridDim.x - 1) / gridDim.x;
+    NPB = (NPB + 63) & ~63ull;
+    NPB = NPB < 64 ? 64 : (NPB > (unsigned long long)NPB_MAX ? (unsigned long long)NPB_MAX : NPB);
     unsigned long long staged_total = 0;
     if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&e.counters[C_FNODES], n_in);
