@@ -27,7 +27,6 @@ constexpr int TD_LD = 25664;             // trace row stride in floats (multiple
 constexpr int TD_OFF_B1 = 25344, TD_OFF_W2 = 25472, TD_OFF_B2 = 25600;
 // factor row of one game: x[198] | 1 | 0 | db1[128] | g·h[128] | g | pad
 constexpr int TD_F_ONE = 198, TD_F_ZERO = 199, TD_F_DB1 = 200, TD_F_GH = 328, TD_F_G = 456, TD_FLD = 464;
-constexpr int TD_GB = 8;                 // games per forward workgroup
 constexpr int TD_TRACE_THREADS = 256;
 constexpr int TD_SLICES = (TD_LD / 4 + TD_TRACE_THREADS - 1) / TD_TRACE_THREADS;   // 26
 constexpr int TD_CHUNK = 8;              // games staged in LDS at a time by the trace kernel
@@ -64,10 +63,12 @@ __global__ void td_gather_kernel(TdView v)
     v.sq[i] = 0.0;
 }
 
-// 8 games x {s_t, s_{t+1}} per workgroup of 128 threads
+// TD_GB games x {s_t, s_{t+1}} per workgroup of 128 threads (2 for small rounds: a shorter FMA chain per thread and
+// more workgroups; 4 for large ones: half the W1 traffic)
+template <int TD_GB>
 __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
 {
-    constexpr int NR = 2 * TD_GB;                         // 16 rows: [s][game]
+    constexpr int NR = 2 * TD_GB;                         // rows: [s][game]
     __shared__ __attribute__((aligned(16))) float xs[N_IN][NR];
     __shared__ float hs[NR][N_HID + 1];
     __shared__ float outs[NR];
@@ -80,9 +81,10 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
 #pragma unroll
     for (int j = 0; j < N_IN; ++j) w[j] = v.w1t[j * N_HID + tid];
 
-    // ---- decode: thread = (row r, chunk c of 3 board points) ----
+    // ---- decode: thread = (row r, chunk c): board points c, c + CH, ... ----
+    constexpr int CH = 128 / NR;                          // chunks (threads per row)
     {
-        const int r = tid & (NR - 1), c = tid >> 4;       // 8 chunks
+        const int r = tid & (NR - 1), c = tid / NR;
         const int s = r / TD_GB, g = r % TD_GB;
         const long long i = i0 + g;
         bool live = i < n_active;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         }
         const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int pt = 3 * c + k;
+        for (int k = 0; k < (24 + CH - 1) / CH; ++k) {
+            const int pt = c + CH * k;
+            if (pt >= 24) break;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int cn = count_at(sd[q], pt + 1);
@@ -151,15 +154,14 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         hs[r][n] = w2 * h[r];
     }
     __syncthreads();
-    // ---- output unit: thread = (row r, eighth e) sums 16 products, 8-lane butterfly ----
+    // ---- output unit: thread = (row r, part e) sums N_HID / CH products, then a CH-lane butterfly ----
     {
-        const int r = tid >> 3, e8 = tid & 7;
+        const int r = tid / CH, e8 = tid % CH;
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += hs[r][e8 * 16 + k];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
+        for (int k = 0; k < N_HID / CH; ++k) s += hs[r][e8 * (N_HID / CH) + k];
+#pragma unroll
+        for (int m = 1; m < CH; m <<= 1) s += __shfl_xor(s, m, 64);
         if (e8 == 0) outs[r] = td_sigmoid(s + v.theta[TD_OFF_B2]);
     }
     __syncthreads();

@@ -1321,7 +1321,10 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         return BGAMD_OK;
     }
     const TdView &v = td->v;
-    hipLaunchKernelGGL(td_forward_kernel, grid1(n_active, TD_GB), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+    if (n_active <= 8192)
+        hipLaunchKernelGGL(td_forward_kernel<2>, grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+    else
+        hipLaunchKernelGGL(td_forward_kernel<4>, grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     // games per group: >= 4, and at most TD_MAX_GROUPS groups
     long long ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
     if (ng < 4) ng = 4;
