@@ -1,8 +1,11 @@
-import sys, time
+"""Soak: hundreds of millions of env steps through every value-net mode (epsilon-greedy every other step) and the
+random policy, with checker conservation and the error flags checked after each phase."""
+import os, sys, time
 import numpy as np, torch
-sys.path[:0] = [__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'backgammon-engine_amd')]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "backgammon-engine_amd")]
 import backgammon_env as bg
-w = np.fromfile(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests/golden/tdgammonNEW100k.f32'), dtype=np.float32)
+w = np.fromfile(os.path.join(ROOT, "tests/golden/tdgammonNEW100k.f32"), dtype=np.float32)
 n = 65536
 env = bg.VecGame(n, seed=777, arena_rows=n*512); env.load_weights(w)
 t0 = time.time()
