@@ -881,3 +881,24 @@ def test_staged_rows_cover_every_distinct_afterstate(bg, O, weights):
             assert got == want, (ply, lane, len(got), len(want))
             rows_total += len(keys); distinct_total += len(want)
     assert distinct_total > 20000 and rows_total < 1.25 * distinct_total
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 777])
+def test_odd_lane_counts(bg, O, weights, n):
+    """Lane counts that are not multiples of any wave / workgroup / tile size: every kernel's tail handling and the
+    size-dependent launch shapes (nodes per stage workgroup, value-net grids) on small envs."""
+    env = bg.VecGame(n, seed=1000 + n)
+    env.load_weights(weights)
+    for t in range(14):
+        pre, pt = _np(env.states()), _np(env.turns())
+        live = (_np(env.flags()) & 4) == 0
+        env.step_greedy(auto_reset=False, epsilon=0.1 if t % 3 == 2 else 0.0)
+        post, dice = _np(env.states()), _np(env.dice())
+        if t % 3 != 2:
+            _check_greedy_step(O, weights, pre, pt, dice, post, [l for l in range(n) if live[l]][:120])
+        p1 = np.clip(post[:, :24], 0, None).sum(1) + post[:, 24] + post[:, 26]
+        p2 = np.clip(-post[:, :24], 0, None).sum(1) + post[:, 25] + post[:, 27]
+        assert (p1 == 15).all() and (p2 == 15).all()
+    for _ in range(6):
+        env.step_random()
+    assert env.stats()["error_flags"] == 0
