@@ -9,8 +9,10 @@ struct NodeState {
     bool dbl;
 };
 
-// node_build: the position of a node from its game's planes + meta (already in registers)
-__device__ __forceinline__ void node_build(const Node &nd, const uint32_t (&p)[8], uint32_t meta, NodeState &s)
+// node_build: the position of a node from its game's planes + meta (already in registers); before_last (optional)
+// receives the position before the node's last move
+__device__ __forceinline__ void node_build(const Node &nd, const uint32_t (&p)[8], uint32_t meta, NodeState &s,
+                                           Side *before_last_own = nullptr, Side *before_last_opp = nullptr)
 {
     s.pl = meta & 1;
     const int d1 = (meta >> 4) & 7, d2 = (meta >> 8) & 7;
@@ -22,7 +24,10 @@ __device__ __forceinline__ void node_build(const Node &nd, const uint32_t (&p)[8
     split_sides(p, s.pl, s.own, s.opp);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-        if (k < s.len) apply_move(s.own, s.opp, s.pl, key_origin(nd.key, k), (k & 1) ? s.dB : s.dA);
+        if (k < s.len) {
+            if (before_last_own && k == s.len - 1) { *before_last_own = s.own; *before_last_opp = s.opp; }
+            apply_move(s.own, s.opp, s.pl, key_origin(nd.key, k), (k & 1) ? s.dB : s.dA);
+        }
 }
 
 __device__ __forceinline__ void node_state(const EnvView &e, const Node &nd, NodeState &s)
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
             NodeState s;
             uint32_t m0 = 0;
             int die = 1;
-            if (valid) node_build(nd, pl_next, meta_next, s);
+            Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
+            if (valid) node_build(nd, pl_next, meta_next, s, &prev_own, &prev_opp);
             if (ni_next < n_in) nd_next = in[ni_next];          // arrives during the rounds below
             if (valid) {
                 die = (s.len & 1) ? s.dB : s.dA;
@@ -189,6 +195,20 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                         Side a = rown, b = ropp;
                         apply_move(a, b, s.pl, y, s.dB);
                         if ((legal_origins(a, b, s.pl, s.dA) >> x) & 1u) dup |= 1u << y;
+                    }
+                    m0 &= ~dup;
+                    pruned_all = m0 == 0;
+                } else if (s.dbl && s.len >= 1 && m0) {
+                    // Doubles: the node's last move was "x", a successor "then y" with y < x has a twin "... y, x" under
+                    // a smaller key whenever y was legal before x and x is still legal after y -- the same moves of the
+                    // same die, the same landing points.  The twin is the one that is expanded.
+                    const int x = key_origin(nd.key, s.len - 1);
+                    uint32_t cand = m0 & ((1u << x) - 1u) & legal_origins(prev_own, prev_opp, s.pl, die), dup = 0;
+                    while (cand) {
+                        const int y = __ffs(cand) - 1; cand &= cand - 1;
+                        Side a = prev_own, b = prev_opp;
+                        apply_move(a, b, s.pl, y, die);
+                        if ((legal_origins(a, b, s.pl, die) >> x) & 1u) dup |= 1u << y;
                     }
                     m0 &= ~dup;
                     pruned_all = m0 == 0;
