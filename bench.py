@@ -229,7 +229,9 @@ def main():
         per = {k: (v["ms"] / (nl if k == "eval" else max(kt2["eval"]["launches"], 1)) if v["launches"] else 0.0) for k, v in kt.items()}
         rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
         fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
-        u_l = steps_l * u_step                                 # distinct afterstates per launch (sampled U per step)
+        # distinct afterstates per launch: U per step sampled on 4 x 2 048 positions after the run, never more than the
+        # rows the launch actually evaluated (every distinct afterstate is one of them)
+        u_l = min(steps_l * u_step, rows_l)
         eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
         # algorithmic bytes: leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
         # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
