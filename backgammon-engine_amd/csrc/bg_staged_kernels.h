@@ -189,12 +189,29 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                     Side rown, ropp;
                     split_sides(pl_next, s.pl, rown, ropp);
                     const int x = key_origin(nd.key, 0);
-                    uint32_t cand = m0 & legal_origins(rown, ropp, s.pl, s.dB), dup = 0;
+                    const uint32_t ma_root = legal_origins(rown, ropp, s.pl, s.dB);
+                    uint32_t cand = m0 & ma_root, dup = 0;
                     while (cand) {
                         const int y = __ffs(cand) - 1; cand &= cand - 1;
                         Side a = rown, b = ropp;
                         apply_move(a, b, s.pl, y, s.dB);
                         if ((legal_origins(a, b, s.pl, s.dA) >> x) & 1u) dup |= 1u << y;
+                    }
+                    // ... and the one checker that takes both dice: "x with d2, on with d1" lands where "x with d1, on
+                    // with d2" does.  Same afterstate iff neither stop-over point holds an opposing checker (a hit on
+                    // the way is the only thing the order can change) and the first order is legal.
+                    {
+                        const int dir = s.pl ? -1 : 1;
+                        const int y2 = x + dir * s.dA, z = x + dir * s.dB;
+                        if (y2 >= 1 && y2 <= 24 && z >= 1 && z <= 24 && ((m0 >> y2) & 1u) && ((ma_root >> x) & 1u)) {
+                            const uint32_t own_any = rown.b[0] | rown.b[1] | rown.b[2] | rown.b[3];
+                            const uint32_t opp_any = ropp.b[0] | ropp.b[1] | ropp.b[2] | ropp.b[3];
+                            if (!((own_any >> y2) & 1u) && !((opp_any >> y2) & 1u) && !((opp_any >> z) & 1u)) {
+                                Side a = rown, b = ropp;
+                                apply_move(a, b, s.pl, x, s.dB);
+                                if ((legal_origins(a, b, s.pl, s.dA) >> z) & 1u) dup |= 1u << y2;
+                            }
+                        }
                     }
                     m0 &= ~dup;
                     pruned_all = m0 == 0;
