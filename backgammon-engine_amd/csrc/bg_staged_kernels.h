@@ -97,66 +97,53 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
     }
 }
 
-// ---- one ply per launch, with exact de-duplication inside the workgroup ------------------------------
-// stage2_kernel<MODE>: a block takes STAGE_THREADS nodes; every node contributes its successor positions
-// (<= 15: one per legal origin; a node with no legal move, or at full depth, contributes itself).  The
-// successors are staged in LDS in rounds of at most STAGE_CAP rows and de-duplicated through an LDS hash
-// (slot = the copy with the SMALLEST reference key among identical (game, 256-bit position)).  Only the
-// representatives leave the CU:
+// ---- one ply per launch ---------------------------------------------------------------------------------------
+// expand_kernel<MODE>: a block takes up to EXPAND_THREADS nodes; every node contributes its successor positions
+// (<= 15: one per legal origin; a node with no legal move, or at full depth, contributes itself):
 //   MODE_PLY2  (in: D1)  children -> D2, stuck nodes -> F      doubles after 2 moves
 //   MODE_PLY3  (in: D2)  everything -> F                       doubles after 3 moves (leaf parents)
 //   MODE_LEAF  (in: F)   everything -> u_rows / u_info         afterstates handed to the value net
-// Dropping a duplicate NODE drops its whole subtree: identical positions have identical subtrees, and the
-// surviving copy has the smaller key prefix, so every afterstate keeps its smallest-key representative.
+// Duplicates are not generated in the first place: of two orders of the same two commuting checker moves only the
+// one with the smaller reference key is expanded (rules below, in the node phase).  What the rules cannot prove equal
+// (about 3 % of the rows: e.g. two different pairs of moves that happen to build the same position) is simply
+// evaluated twice -- identical rows get bit-identical values and the arg-max keeps the smaller key, so the result is
+// the same.  An earlier version staged every successor in LDS and removed duplicates exactly through an LDS hash
+// (40 B per row, CAS chains, five barriers per 1 024 rows); with the rules in place that machinery removed 3 % of the
+// rows and cost a third of the step.
+//
+// One LANE PER SUCCESSOR: the node threads only publish their position (11 dwords in LDS) and their successor count;
+// after the scan and ONE allocation per block every successor gets its own lane, which finds its parent by binary
+// search over the offsets, rebuilds the position and writes it to its final place (lane q -> row base + q: coalesced,
+// and the rows leave in reference order of the nodes).
 enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
-constexpr int STAGE_THREADS = 512;
-// staged rows per round (40 B each, SoA): the doubles plies get the wide de-dup window (their duplicates
-// multiply downstream), the leaf stage the narrow one (three resident blocks per CU instead of one)
-__host__ __device__ constexpr int stage_cap(int mode) { return mode == 3 ? 1024 : 2048; }
-__host__ __device__ constexpr int stage_blocks_per_cu(int mode) { return 160 * 1024 / (stage_cap(mode) * 50 + 256); }
-constexpr uint32_t STAGE_EMPTY = 0xFFFFFFFFu;
+constexpr int EXPAND_THREADS = 256;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
-constexpr uint32_t INFO_SELF = 0x40000000u;   // staged entry is the node itself (stuck), not a child
 
-// One LANE PER SUCCESSOR: the node threads only publish their position (11 dwords in LDS) and their successor
-// count; after the scan every successor gets its own lane, which rebuilds it from the parent record, stages it and
-// inserts it into the hash in one go (a thread walking its node's <= 15 successors leaves most lanes idle).
 template <int MODE>
-__global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, StagedView sv)
+__global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel(EnvView e, StagedView sv)
 {
-    constexpr int NT = STAGE_THREADS;
-    // nodes per block iteration.  The doubles plies have few nodes (tens of thousands per launch) and live on the LDS
-    // latency of the hash phase: a quarter / half of the threads take a node, so a block stages ~1-2 successors per
-    // lane instead of ~5 in sequence and the nodes spread over all CUs instead of a fifth of them
-    constexpr int NPB_MAX = MODE == MODE_PLY2 ? NT / 4 : (MODE == MODE_PLY3 ? NT / 2 : NT);
-    constexpr int CAP = stage_cap(MODE);
-    constexpr int TSLOTS = 2 * CAP;
+    constexpr int NT = EXPAND_THREADS;
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
-    __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | SELF-less | turn<<31
-    __shared__ uint16_t s_par_of[CAP];         // successor (window slot) -> parent thread
-    __shared__ uint32_t s_row[10][CAP];
-    __shared__ uint32_t s_tab[TSLOTS];
-    __shared__ uint16_t s_pos[CAP];
+    __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31
     __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
     const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
     const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
     unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
     if (n_in > cap_in) n_in = cap_in;
-    // ... and when the launch has fewer nodes than that per workgroup (small envs), they are spread over the whole
-    // grid, 64 at least (a game's nodes stay together for the de-duplication): one short round instead of several
+    // nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole
+    // grid, 64 per workgroup at least
     unsigned long long NPB = (n_in + gridDim.x - 1) / gridDim.x;
     NPB = (NPB + 63) & ~63ull;
-    NPB = NPB < 64 ? 64 : (NPB > (unsigned long long)NPB_MAX ? (unsigned long long)NPB_MAX : NPB);
+    NPB = NPB < 64 ? 64 : (NPB > (unsigned long long)NT ? (unsigned long long)NT : NPB);
     unsigned long long staged_total = 0;
     if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
     // software pipeline over block iterations: the node of the NEXT iteration is loaded at the start of this one and
-    // its game's planes are gathered once it has arrived (after the staging rounds), so neither global round trip
-    // sits on the next iteration's critical path
+    // its game's planes are gathered once it has arrived, so neither global round trip sits on the critical path
     Node nd_next{0u, 0u};
     uint32_t pl_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}, meta_next = 0;
     {
@@ -167,15 +154,15 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
         const unsigned long long ni = blk * NPB + threadIdx.x;
         const bool valid = threadIdx.x < NPB && ni < n_in;
         const unsigned long long ni_next = threadIdx.x < NPB ? (blk + gridDim.x) * NPB + threadIdx.x : ~0ull;
-        uint32_t cnt = 0;
+        uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
+        Node nd = nd_next;
         {
-            const Node nd = nd_next;
             NodeState s;
             uint32_t m0 = 0;
             int die = 1;
             Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
             if (valid) node_build(nd, pl_next, meta_next, s, &prev_own, &prev_opp);
-            if (ni_next < n_in) nd_next = in[ni_next];          // arrives during the rounds below
+            if (ni_next < n_in) nd_next = in[ni_next];          // arrives during the successor phase below
             if (valid) {
                 die = (s.len & 1) ? s.dB : s.dA;
                 if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
@@ -184,8 +171,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                     // Non-doubles, second die order: this node is "x with d2", its successors are "then y with d1".
                     // If y was a legal FIRST move with d1 and x is then legal with d2, the first die order already
                     // produced (y, x) -- the same two checker moves, the same landing points, hence the same
-                    // afterstate under a smaller key.  Such successors are not generated at all (about a third of
-                    // the staged leaves); whatever this test does not prove equal still goes through the hash.
+                    // afterstate under a smaller key.  Such successors are not generated.
                     Side rown, ropp;
                     split_sides(pl_next, s.pl, rown, ropp);
                     const int x = key_origin(nd.key, 0);
@@ -230,7 +216,9 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                     m0 &= ~dup;
                     pruned_all = m0 == 0;
                 }
-                cnt = m0 ? (uint32_t)__popc(m0) : (pruned_all ? 0u : 1u);
+                const bool stuck = m0 == 0 && !pruned_all;     // no legal move (or full depth): the node itself goes on
+                if (MODE == MODE_PLY2) { cnt = (uint32_t)__popc(m0); cntB = stuck ? 1u : 0u; }
+                else cnt = m0 ? (uint32_t)__popc(m0) : (stuck ? 1u : 0u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s_par_plane[k][threadIdx.x] = s.own.b[k]; s_par_plane[4 + k][threadIdx.x] = s.opp.b[k]; }
                 s_par_mask[threadIdx.x] = m0;
@@ -238,20 +226,32 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                 s_par_key[threadIdx.x] = nd.key | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
             }
         }
-        uint32_t total;
-        const uint32_t off = block_scan_256<NW, false>(cnt, &total, s_wave);   // barrier at the end of the last round
+        uint32_t total, totB = 0;
+        const uint32_t off = block_scan_256<NW, true>(cnt, &total, s_wave);
         s_par_off[threadIdx.x] = off;
         staged_total += total;
-        for (uint32_t r0 = 0; r0 < total; r0 += CAP) {
-            const uint32_t nrow = total - r0 < (uint32_t)CAP ? total - r0 : (uint32_t)CAP;
-            for (int i = threadIdx.x; i < TSLOTS; i += NT) s_tab[i] = STAGE_EMPTY;
-            // successor -> parent map of this round's window
-            for (uint32_t j = (off > r0 ? off : r0); j < off + cnt && j < r0 + nrow; ++j) s_par_of[j - r0] = (uint16_t)threadIdx.x;
-            __syncthreads();
-            // one lane per successor: rebuild, stage, hash
-            for (uint32_t q = threadIdx.x; q < nrow; q += NT) {
-                const uint32_t par = s_par_of[q];
-                uint32_t rank = r0 + q - s_par_off[par];
+        unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
+        const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
+        const unsigned long long baseA = block_alloc<false>(topA, total, &s_slot);      // the scan just synchronised
+        bool ok = baseA + total <= capA;
+        if (MODE == MODE_PLY2) {                               // stuck doubles nodes are leaf parents as they are
+            const uint32_t offB = block_scan_256<NW, true>(cntB, &totB, s_wave);
+            const unsigned long long baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
+            ok = ok && baseB + totB <= (unsigned long long)sv.cap_f;
+            if (ok && cntB) sv.f[baseB + offB] = Node{nd.game, nd.key};
+        }
+        if (!ok) flag_overflow(e);
+        __syncthreads();                                       // parent records and offsets are in place
+        if (ok) {
+            const int np = (int)NPB;
+            for (uint32_t q = threadIdx.x; q < total; q += NT) {
+                int lo = 0, hi = np - 1;                       // last parent whose offset is <= q
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_par_off[mid] <= q) lo = mid; else hi = mid - 1;
+                }
+                const int par = lo;
+                uint32_t rank = q - s_par_off[par];
                 uint32_t m = s_par_mask[par];
                 const uint32_t pk = s_par_key[par];
                 const int pl = (int)(pk >> 31), die = (int)((pk >> 27) & 7u);
@@ -263,78 +263,20 @@ __global__ __launch_bounds__(STAGE_THREADS) void stage2_kernel(EnvView e, Staged
                     const int o = __ffs(m) - 1;
                     apply_move(a, b, pl, o, die);
                     key = key_child(key, o);
-                } else key |= INFO_SELF;
-                key |= pl ? 0x80000000u : 0u;
-                const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
+                }
                 const uint32_t game = s_par_game[par];
-                const uint32_t p[8] = {s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3], s2.b[0], s2.b[1], s2.b[2], s2.b[3]};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s_row[k][q] = p[k];
-                s_row[8][q] = game; s_row[9][q] = key;
-                // (LDS operations of a wave retire in order: the row is in place before the CAS publishes q)
-                uint32_t h = hash_row(p, game) & (TSLOTS - 1);
-                for (;;) {
-                    const uint32_t cur = atomicCAS(&s_tab[h], STAGE_EMPTY, q);
-                    if (cur == STAGE_EMPTY) break;
-                    bool same = s_row[8][cur] == game;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) same = same && (s_row[k][cur] == p[k]);
-                    if (same) {
-                        const uint32_t mykey = key & KEY_MASK;
-                        uint32_t c = cur;
-                        while (mykey < (s_row[9][c] & KEY_MASK)) {
-                            const uint32_t old = atomicCAS(&s_tab[h], c, q);
-                            if (old == c) break;
-                            c = old;
-                        }
-                        break;
-                    }
-                    h = (h + 1) & (TSLOTS - 1);
-                }
-                s_pos[q] = (uint16_t)h;
+                const unsigned long long d = baseA + q;
+                if (MODE == MODE_LEAF) {
+                    const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
+                    sv.u_rows[2 * d] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
+                    sv.u_rows[2 * d + 1] = make_uint4(s2.b[0], s2.b[1], s2.b[2], s2.b[3]);
+                    sv.u_info[d] = make_uint2(game, key | (pl ? 0x80000000u : 0u));
+                } else if (MODE == MODE_PLY2) sv.d2[d] = Node{game, key};
+                else sv.f[d] = Node{game, key};
             }
-            __syncthreads();
-            // representatives leave the CU, a contiguous slice per thread (order-preserving)
-            const uint32_t slice = (nrow + NT - 1) / NT;
-            const uint32_t lo = threadIdx.x * slice, hi = lo + slice < nrow ? lo + slice : nrow;
-            uint32_t mineA = 0, mineB = 0;
-            for (uint32_t i = lo; i < hi; ++i) {
-                if (s_tab[s_pos[i]] != i) continue;
-                if (MODE == MODE_PLY2 && (s_row[9][i] & INFO_SELF)) ++mineB; else ++mineA;
-            }
-            uint32_t totA, totB = 0;
-            uint32_t offA = block_scan_256<NW, false>(mineA, &totA, s_wave);     // barrier after the insert phase
-            unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
-            const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
-            const unsigned long long baseA = block_alloc<false>(topA, totA, &s_slot);   // the scan just synchronised
-            uint32_t offB = 0;
-            unsigned long long baseB = 0;
-            if (MODE == MODE_PLY2) {
-                offB = block_scan_256<NW>(mineB, &totB, s_wave);
-                baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
-            }
-            const bool ok = baseA + totA <= capA && baseB + totB <= (unsigned long long)sv.cap_f;
-            if (!ok) flag_overflow(e);
-            if (ok) {
-                for (uint32_t i = lo; i < hi; ++i) {
-                    if (s_tab[s_pos[i]] != i) continue;
-                    const uint32_t info = s_row[9][i];
-                    if (MODE == MODE_LEAF) {
-                        const unsigned long long d = baseA + offA++;
-                        sv.u_rows[2 * d] = make_uint4(s_row[0][i], s_row[1][i], s_row[2][i], s_row[3][i]);
-                        sv.u_rows[2 * d + 1] = make_uint4(s_row[4][i], s_row[5][i], s_row[6][i], s_row[7][i]);
-                        sv.u_info[d] = make_uint2(s_row[8][i], info & ~INFO_SELF);
-                    } else {
-                        const Node out{s_row[8][i], info & 0x3FFFFFFFu & ~(7u << 27)};
-                        if (MODE == MODE_PLY2 && (info & INFO_SELF)) sv.f[baseB + offB++] = out;
-                        else if (MODE == MODE_PLY2) sv.d2[baseA + offA++] = out;
-                        else sv.f[baseA + offA++] = out;
-                    }
-                }
-            }
-            __syncthreads();
         }
         if (ni_next < n_in) { load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
+        __syncthreads();                                       // the records are reused by the next iteration
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
 }

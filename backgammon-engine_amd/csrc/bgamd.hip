@@ -968,14 +968,9 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     StagedView &sv = env->sv;
     const long long n = env->v.n;
     HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
-    auto sgrid = [&](long long max_items, int mode) {     // persistent grid sized by LDS-limited residency
-        long long b = (max_items + STAGE_THREADS - 1) / STAGE_THREADS;
-        const long long lim = (long long)env->n_cu * stage_blocks_per_cu(mode);
-        return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
-    };
-    auto sgrid2 = [&](long long max_items) {            // stage2_kernel<LEAF>: 77 KB of LDS -> two blocks per CU
-        long long b = (max_items + STAGE_THREADS - 1) / STAGE_THREADS;
-        const long long lim = (long long)env->n_cu * 2;
+    auto egrid = [&](long long max_items) {              // expand_kernel: 12 KB of LDS, 256 threads -> 8 blocks per CU
+        long long b = (max_items + EXPAND_THREADS - 1) / EXPAND_THREADS;
+        const long long lim = (long long)env->n_cu * 8;
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
     };
     const bool incremental = precision == BGAMD_F32;
@@ -1012,12 +1007,12 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     }
     {
         KTimer t(env, s, 4);
-        hipLaunchKernelGGL(stage2_kernel<MODE_PLY2>, sgrid(n * 15, MODE_PLY2), dim3(STAGE_THREADS), 0, s, env->v, sv);
-        hipLaunchKernelGGL(stage2_kernel<MODE_PLY3>, sgrid(n * 225, MODE_PLY3), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3), dim3(EXPAND_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6), dim3(EXPAND_THREADS), 0, s, env->v, sv);
     }
     {
         KTimer t(env, s, 5);
-        hipLaunchKernelGGL(stage2_kernel<MODE_LEAF>, sgrid2(n * 3375), dim3(STAGE_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16), dim3(EXPAND_THREADS), 0, s, env->v, sv);
     }
     if (incremental) {
         if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
