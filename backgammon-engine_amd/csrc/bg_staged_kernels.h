@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
 }
 
 // ---- one ply per launch ---------------------------------------------------------------------------------------
-// expand_kernel<MODE>: a block takes up to EXPAND_THREADS nodes; every node contributes its successor positions
+// expand_kernel<MODE>: a block takes up to expand_threads(MODE) nodes; every node contributes its successor positions
 // (<= 15: one per legal origin; a node with no legal move, or at full depth, contributes itself):
 //   MODE_PLY2  (in: D1)  children -> D2, stuck nodes -> F      doubles after 2 moves
 //   MODE_PLY3  (in: D2)  everything -> F                       doubles after 3 moves (leaf parents)
@@ -116,13 +116,21 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
 // search over the offsets, rebuilds the position and writes it to its final place (lane q -> row base + q: coalesced,
 // and the rows leave in reference order of the nodes).
 enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
-constexpr int EXPAND_THREADS = 256;
+// threads per workgroup: every block iteration costs one same-address allocation atomic, so the leaf stage (2 000
+// block iterations of 256) takes big workgroups; the doubles plies are small and latency-bound and take smaller ones
+#ifndef BG_EXPAND_NT_PLY
+#define BG_EXPAND_NT_PLY 512
+#endif
+#ifndef BG_EXPAND_NT_LEAF
+#define BG_EXPAND_NT_LEAF 1024
+#endif
+__host__ __device__ constexpr int expand_threads(int mode) { return mode == 3 ? BG_EXPAND_NT_LEAF : BG_EXPAND_NT_PLY; }
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 
 template <int MODE>
-__global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel(EnvView e, StagedView sv)
+__global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e, StagedView sv)
 {
-    constexpr int NT = EXPAND_THREADS;
+    constexpr int NT = expand_threads(MODE);
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
     __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31

@@ -968,9 +968,10 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     StagedView &sv = env->sv;
     const long long n = env->v.n;
     HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
-    auto egrid = [&](long long max_items) {              // expand_kernel: 12 KB of LDS, 256 threads -> 8 blocks per CU
-        long long b = (max_items + EXPAND_THREADS - 1) / EXPAND_THREADS;
-        const long long lim = (long long)env->n_cu * 8;
+    auto egrid = [&](long long max_items, int mode) {    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
+        const int nt = expand_threads(mode);
+        long long b = (max_items + nt - 1) / nt;
+        const long long lim = (long long)env->n_cu * (2048 / nt);
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
     };
     const bool incremental = precision == BGAMD_F32;
@@ -1007,12 +1008,12 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     }
     {
         KTimer t(env, s, 4);
-        hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3), dim3(EXPAND_THREADS), 0, s, env->v, sv);
-        hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6), dim3(EXPAND_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6, MODE_PLY3), dim3(expand_threads(MODE_PLY3)), 0, s, env->v, sv);
     }
     {
         KTimer t(env, s, 5);
-        hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16), dim3(EXPAND_THREADS), 0, s, env->v, sv);
+        hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
     }
     if (incremental) {
         if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
