@@ -2,16 +2,17 @@
 // ply per kernel ("node" = game + move prefix), so no lane ever walks more than one node:
 //
 //   roots_kernel         lane per game : roll, first-ply moves      -> D1 (doubles) / F (leaf parents)
-//   stage2_kernel<PLY2/3> lane per node : doubles ply 2 and 3, children staged in LDS and de-duplicated -> D2 / F
-//   stage2_kernel<LEAF>  lane per F node: <= 15 afterstates each, staged in LDS, de-duplicated through an
-//                        LDS hash (exact 256-bit compare)      -> unique rows + (game, key)
+//   expand_kernel<PLY2/3> lane per node, then lane per child : doubles ply 2 and 3          -> D2 / F
+//   expand_kernel<LEAF>  lane per F node, then lane per afterstate (<= 15 each)             -> rows + (game, key)
+//                        (of two orders of the same commuting moves only the smaller-key one is expanded)
 //   eval kernel     (bg_eval.h)   : value per unique row, atomicMax of (value, ~key) per game
 //   apply_kernel    lane per game : decode the winning key, replay its <= 4 moves, terminal/reset
 //
 // Reference order is carried by the KEY instead of by position: key = pass | o0 | o1 | o2 | o3 | len
 // compares exactly like the index into legalTurnSequences' list (cppsrc/game.cpp:134-191: d1-first
 // block then d2-first block, ascending origins, DFS pre-order for doubles), so "first index wins
-// ties" (model.py:212-213) is "smallest key wins" and duplicates can be dropped anywhere.
+// ties" (model.py:212-213) is "smallest key wins": duplicates can be dropped anywhere, and a duplicate that is kept
+// (identical row, identical value) cannot change the result.
 #pragma once
 #include "bg_board.h"
 
@@ -78,17 +79,5 @@ struct StagedView {
     unsigned long long *tops;             // [T_COUNT]
 };
 enum { T_D1 = 0, T_D2, T_F, T_U, T_COUNT };
-
-__device__ __forceinline__ uint32_t hash_row(const uint32_t (&p)[8], uint32_t game)
-{
-    uint32_t h = game * 0x9E3779B1u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        h ^= p[k];
-        h *= 0x85EBCA6Bu;
-        h ^= h >> 15;
-    }
-    return h;
-}
 
 }  // namespace bg

@@ -274,9 +274,9 @@ def main():
                                "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"})
         roofs = {
             "eval": ev,
-            "leaves": {"kernel": "leaves_kernel", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
+            "leaves": {"kernel": "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
-            "expand": {"kernel": "roots_kernel+expand_kernel<1,2>", "bound": "hbm", "achieved": round(expand_gbs, 2),
+            "expand": {"kernel": "roots_kernel+expand_kernel<PLY2,PLY3>", "bound": "hbm", "achieved": round(expand_gbs, 2),
                        "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
                        "avg_ms": round(per["expand"], 4)},
         }
@@ -284,7 +284,7 @@ def main():
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "stage2_kernel<3>")):
+            for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_kernel<3>")):
                 if key in pmc:
                     roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
                     roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per launch)"

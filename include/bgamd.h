@@ -149,7 +149,7 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
                           int32_t *d_n, int8_t *d_pairs /*[n,26,2]*/, void *stream);
 
 /* diagnostics: (game, key | turn<<31) of every row the value net evaluated in the last greedy step (after the
- * in-workgroup de-duplication); returns the row count (synchronises). */
+ * pruning of commuting move orders: a few per cent of the rows are still copies); returns the row count (synchronises). */
 int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info /* uint32[cap][2] */, int64_t cap, void *stream);
 
 /* ---- trajectory log for the learner (the list of encodings play_game returns, train.py:105-106,
@@ -170,7 +170,7 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
 /* kernel timing hook for bench.py: brackets kernel groups with HIP events on the launch stream;
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
  * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
- * 4 roots+expand (plies 1-3), 5 leaves+dedup, 6 root term of the incremental value net (on the env's second stream,
+ * 4 roots+expand (plies 1-3), 5 leaf stage, 6 root term of the incremental value net (on the env's second stream,
  * beside the doubles plies; BGAMD_NO_OVERLAP=1 in the environment keeps it on the caller's stream).  enable: 0 = off, 1 = every group, (mask << 8) = only the groups
  * whose bit is set in mask (each bracket costs two event records, ~2-3 us per step). */
 int bgamd_env_time_kernels(bgamd_env *env, int enable);

@@ -852,7 +852,7 @@ def _replay_key(O, pre28, turn, d1, d2, key):
 def test_staged_rows_cover_every_distinct_afterstate(bg, O, weights):
     """What the value net is handed in a greedy step: every key replays (through the oracle's tryMove) to a legal
     afterstate, and the set of those afterstates is EXACTLY the set of distinct afterstates of the reference-order
-    enumeration -- the de-duplication drops copies, never a position."""
+    enumeration -- the pruning of commuting move orders drops copies, never a position."""
     n = 1024
     env = bg.VecGame(n, seed=2024)
     env.load_weights(weights)
