@@ -231,6 +231,12 @@ class VecGame:
                                                     (WANT_INDEX if want_index else 0), float(epsilon),
                                                     int(precision), _stream()), "step_greedy")
 
+    def run_greedy(self, n_steps, roll=True, auto_reset=True, epsilon=0.0, precision=F32, only_player=None, slot=0):
+        """n_steps greedy steps in one call: the same games as n_steps calls of step_greedy, with the apply of one
+        step and the roots of the next sharing a launch."""
+        _capi.check(self._lib.bgamd_env_run_greedy(self._h, self._flags(roll, auto_reset, False, only_player, slot),
+                                                   float(epsilon), int(precision), int(n_steps), _stream()), "run_greedy")
+
     def last_choice(self):
         ch, cnt = self._buf((self.n,), torch.int32), self._buf((self.n,), torch.int32)
         sq, ln = self._buf((self.n, 4, 2), torch.int8), self._buf((self.n,), torch.int32)

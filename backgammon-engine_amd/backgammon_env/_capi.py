@@ -42,6 +42,7 @@ SYMBOLS = [
     ("bgamd_env_load_weights", C.c_int, [_P, _P]),
     ("bgamd_env_load_weights_slot", C.c_int, [_P, C.c_int, _P]),
     ("bgamd_env_step_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, _P]),
+    ("bgamd_env_run_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, C.c_int64, _P]),
     ("bgamd_env_last_choice", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("bgamd_env_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("bgamd_env_reset_stats", C.c_int, [_P, _P]),

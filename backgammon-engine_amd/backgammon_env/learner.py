@@ -216,9 +216,12 @@ def play_round(env, max_plies: int = 512, epsilon: float = 0.0, precision=0):
     ONE game to the end, turns are logged. -> (rows [T, n, 8] int32, lengths [n], p1_won [n] bool)."""
     traj = env.record_trajectory(max_plies)
     env.reset()
-    for _ in range(max_plies):
-        env.step_greedy(auto_reset=False, epsilon=epsilon, precision=precision)
-        if _ % 16 == 15 and bool(((env.flags() & 4) != 0).all()):
+    done_steps = 0
+    while done_steps < max_plies:                      # 16 turns per call; finished games are frozen and skipped
+        k = min(16, max_plies - done_steps)
+        env.run_greedy(k, auto_reset=False, epsilon=epsilon, precision=precision)
+        done_steps += k
+        if bool(((env.flags() & 4) != 0).all()):
             break
     flags = env.flags()
     done = (flags & 4) != 0

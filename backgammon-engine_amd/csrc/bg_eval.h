@@ -347,8 +347,11 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
     const float *__restrict__ b2p, const uint4 *__restrict__ root_rows, const float *__restrict__ root_hidden,
     float *__restrict__ values, const uint2 *__restrict__ info, unsigned long long *__restrict__ best,
-    unsigned long long *__restrict__ delta_counter)
+    unsigned long long *__restrict__ delta_counter, unsigned long long *__restrict__ zero_words, int n_zero_words)
 {
+    // multi-step runs: the OTHER set of list counters is cleared here, while no kernel is using it, for the roots of
+    // the next step (which share a launch with this step's apply)
+    if (zero_words && blockIdx.x == 0 && (int)threadIdx.x < n_zero_words) zero_words[threadIdx.x] = 0ull;
     extern __shared__ float4 sW[];                       // [DW_ROWS][33] float4, then w2[128], then the lists
     float *sW2 = reinterpret_cast<float *>(sW) + DELTA_W_FLOATS;
     uint16_t *sList = reinterpret_cast<uint16_t *>(sW2 + N_HID) + (threadIdx.x >> 6) * (DELTA_MAX * 64);

@@ -43,11 +43,10 @@ __device__ __forceinline__ void flag_overflow(const EnvView &e)
 }
 
 // ---- ply 1: lane per game -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, int flags)
+__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_slot;
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     LaneCtx c;
     lane_begin(e, g, flags, c);
     Side own, opp;
@@ -95,6 +94,11 @@ __global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, in
         sv.root_rows[2 * g] = make_uint4(c.p[0] | (c.turn ? TURN_BIT : 0u), c.p[1], c.p[2], c.p[3]);
         sv.root_rows[2 * g + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
     }
+}
+
+__global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, int flags)
+{
+    roots_body(e, sv, flags, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- one ply per launch ---------------------------------------------------------------------------------------
@@ -307,9 +311,9 @@ struct ExploreView {                                       // counted tasks of t
 __device__ __forceinline__ bool explore_pick(const EnvView &e, const ExploreView &xv, long long g, uint32_t u, Side &own,
                                              Side &opp, uint32_t &key, uint32_t &k, uint32_t &C);
 
-__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
+__device__ __forceinline__ void apply_body(const EnvView &e, const StagedView &sv, const ExploreView &xv, int flags, float epsilon,
+                                           long long g)
 {
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     LaneCtx c;
     lane_begin(e, g, flags & ~BGAMD_ROLL, c);            // dice were stored by roots_kernel
     const unsigned long long pack = (g < e.n && c.live) ? sv.best[g] : 0ull;
@@ -353,4 +357,21 @@ __global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, Ex
     }
     if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.chosen_val[g] = cval; e.cand_cnt[g] = ccount; }
     finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
+{
+    apply_body(e, sv, xv, flags, epsilon, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Step boundary of a multi-step run: the apply of step t and the roots of step t+1 for the same lane in one launch
+// (the lane's new position is read back by the thread that just stored it).  sv_next carries the other set of list
+// counters: the value-net kernel of step t cleared it while nothing was using it.
+__global__ __launch_bounds__(256) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
+                                                       float epsilon)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    apply_body(e, sv, xv, flags, epsilon, g);
+    __syncthreads();                                    // finish_turn's statistics scratch is free again
+    roots_body(e, sv_next, flags, g);
 }

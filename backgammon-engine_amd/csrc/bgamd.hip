@@ -549,6 +549,7 @@ struct bgamd_env {
     int n_cu = 256;
     hipStream_t side = nullptr;            // second stream: the root pass of the value net runs beside the doubles plies
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
+    unsigned long long *tops_base = nullptr;   // [2][T_COUNT]; sv.tops points at the set of the last step
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
@@ -713,10 +714,14 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&sv.best, n * 8));
         HIPCHK(hipMalloc(&sv.root_rows, n * 32));
         HIPCHK(hipMalloc(&sv.root_hidden, n * N_HID * 4));
-        HIPCHK(hipMalloc(&sv.tops, T_COUNT * 8));
-        HIPCHK(hipMemset(sv.tops, 0, T_COUNT * 8));
+        HIPCHK(hipMalloc(&sv.tops, 2 * T_COUNT * 8));             // two sets: consecutive steps of a run alternate
+        HIPCHK(hipMemset(sv.tops, 0, 2 * T_COUNT * 8));
+        env->tops_base = sv.tops;
         RandomView &rv = env->rv;                    // bounded random-policy step (bg_random_kernels.h)
-        rv.tasks = sv.f; rv.cap = sv.cap_f; rv.top = &sv.tops[T_F];
+        rv.cap = sv.cap_f;                           // own task list and counter: a step boundary of a multi-step run
+        HIPCHK(hipMalloc(&rv.tasks, (size_t)rv.cap * sizeof(Node)));   // reads the tasks while the next roots write sv.f
+        HIPCHK(hipMalloc(&rv.top, 8));
+        HIPCHK(hipMemset(rv.top, 0, 8));
         HIPCHK(hipMalloc(&rv.task_count, (size_t)rv.cap * 4));
         HIPCHK(hipMalloc(&rv.task_off, n * 4));
         HIPCHK(hipMalloc(&rv.task_n, n * 4));
@@ -737,7 +742,7 @@ int bgamd_env_destroy(bgamd_env *env)
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
                     v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
-                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->sv.tops, env->rv.task_count, env->rv.task_off, env->rv.task_n};
+                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
     if (env->ev_fork) hipEventDestroy(env->ev_fork);
@@ -868,7 +873,7 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
     if (!env) return BGAMD_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const long long n = env->v.n;
-    HIPCHK(hipMemsetAsync(&env->sv.tops[T_F], 0, 8, s));
+    HIPCHK(hipMemsetAsync(env->rv.top, 0, 8, s));
     {
         KTimer t(env, s, 3);
         hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags, -1.0f);
@@ -958,16 +963,17 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
     return BGAMD_OK;
 }
 
-int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream)
+int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision, int64_t n_steps, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    if (!env || n_steps < 0) return BGAMD_E_INVALID;
     const int slot = (flags & BGAMD_WEIGHTS_SLOT1) ? 1 : 0;
     if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
+    if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2 && precision != BGAMD_F32_DENSE)
+        return BGAMD_E_INVALID;
+    if (n_steps == 0) return BGAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    StagedView &sv = env->sv;
     const long long n = env->v.n;
-    HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
     auto egrid = [&](long long max_items, int mode) {    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
         const int nt = expand_threads(mode);
         long long b = (max_items + nt - 1) / nt;
@@ -976,74 +982,102 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
     };
     const bool incremental = precision == BGAMD_F32;
     const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    // two sets of list counters: step t uses set t & 1.  Inside a run the apply of step t and the roots of step t+1
+    // share one launch (boundary_kernel); the value-net kernel of step t clears the set those roots allocate from.
+    HIPCHK(hipMemsetAsync(env->tops_base, 0, 2 * T_COUNT * 8, s));
+    int parity = 0;
+    StagedView sv = env->sv;
+    sv.tops = env->tops_base;
     {
         KTimer t(env, s, 4);
         hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
     }
-    if (incremental) {
-        // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows roots_kernel just wrote.
-        // It runs on the env's second stream beside the doubles plies -- two small latency-bound launches that leave
-        // most of the chip idle -- and is joined before the incremental kernel.
-        hipStream_t s2 = env->overlap ? env->side : s;
-        if (env->overlap) {
-            HIPCHK(hipEventRecord(env->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(s2, env->ev_fork, 0));
+    for (int64_t step = 0; step < n_steps; ++step) {
+        if (incremental) {
+            // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
+            // It runs on the env's second stream beside the doubles plies -- small latency-bound launches that leave
+            // most of the chip idle -- and is joined before the incremental kernel.
+            hipStream_t s2 = env->overlap ? env->side : s;
+            if (env->overlap) {
+                HIPCHK(hipEventRecord(env->ev_fork, s));
+                HIPCHK(hipStreamWaitEvent(s2, env->ev_fork, 0));
+            }
+            {
+                KTimer t(env, s2, 6);
+                if (env->root_f32_mfma)
+                    hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
+                                       (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
+                                       (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
+                                       (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+                else {
+                    long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
+                    if (blocks > env->n_cu) blocks = env->n_cu;
+                    hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
+                                       ROOT3_LDS_TOTAL, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
+                                       (const uint2 *)env->d_lut, b1, sv.root_hidden);
+                }
+            }
+            if (env->overlap) HIPCHK(hipEventRecord(env->ev_join, s2));
         }
         {
-            KTimer t(env, s2, 6);
-            if (env->root_f32_mfma)
-                hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
-                                   (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
-                                   (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
-                                   (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-            else {
-                long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
-                if (blocks > env->n_cu) blocks = env->n_cu;
-                hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
-                                   ROOT3_LDS_TOTAL, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
-                                   (const uint2 *)env->d_lut, b1, sv.root_hidden);
-            }
+            KTimer t(env, s, 4);
+            hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6, MODE_PLY3), dim3(expand_threads(MODE_PLY3)), 0, s, env->v, sv);
         }
-        if (env->overlap) HIPCHK(hipEventRecord(env->ev_join, s2));
-    }
-    {
-        KTimer t(env, s, 4);
-        hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
-        hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6, MODE_PLY3), dim3(expand_threads(MODE_PLY3)), 0, s, env->v, sv);
-    }
-    {
-        KTimer t(env, s, 5);
-        hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
-    }
-    if (incremental) {
-        if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
-        KTimer t(env, s, 1);
-        // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
-        long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
-        dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
-        hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
-                           (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
-                           (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
-                           env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS]);
-    } else {
-        rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
-        if (rc) return rc;
-    }
-    ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};
-    if (epsilon > 0.0f) {                                  // the leaf-parent list is free again: it holds the tasks
-        KTimer t(env, s, 3);
-        HIPCHK(hipMemsetAsync(&sv.tops[T_F], 0, 8, s));
-        hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags & ~BGAMD_ROLL, epsilon);
-        long long b = (n * 4 + 255) / 256;
-        const long long lim = (long long)env->n_cu * 8;
-        hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
-    }
-    {
-        KTimer t(env, s, 2);
-        hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, xv, flags, epsilon);
+        {
+            KTimer t(env, s, 5);
+            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
+        }
+        const bool more = step + 1 < n_steps;
+        const bool fused = more && incremental;                // the dense kernels do not clear the other counter set
+        StagedView sv_next = sv;
+        sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
+        if (incremental) {
+            if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
+            KTimer t(env, s, 1);
+            // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
+            long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
+            dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
+            hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
+                               (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
+                               (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
+                               env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS],
+                               fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT);
+        } else {
+            rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
+            if (rc) return rc;
+        }
+        ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};
+        if (epsilon > 0.0f) {                              // exploring lanes pick through their counted tasks (bounded work)
+            KTimer t(env, s, 3);
+            HIPCHK(hipMemsetAsync(env->rv.top, 0, 8, s));
+            hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags & ~BGAMD_ROLL, epsilon);
+            long long b = (n * 4 + 255) / 256;
+            const long long lim = (long long)env->n_cu * 8;
+            hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
+        }
+        {
+            KTimer t(env, s, 2);
+            if (fused)
+                hipLaunchKernelGGL(boundary_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, sv_next, xv, flags, epsilon);
+            else
+                hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, xv, flags, epsilon);
+        }
+        env->sv.tops = sv.tops;                                // the set whose T_U describes the last evaluated rows
+        if (fused) { parity ^= 1; sv = sv_next; }
+        else if (more) {                                       // dense value-net modes: plain per-step sequence
+            HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
+            KTimer t(env, s, 4);
+            hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
+        }
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
+}
+
+int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream)
+{
+    return bgamd_env_run_greedy(env, flags, epsilon, precision, 1, stream);
 }
 
 int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq, int32_t *d_seq_len,

@@ -130,6 +130,10 @@ int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choi
 int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);   /* slot 0 */
 int bgamd_env_load_weights_slot(bgamd_env *env, int slot /* 0 | 1 */, const float *h_weights);
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);
+/* n_steps greedy steps back to back (the loop body of play_game, train.py:103-121, n_steps times for every lane),
+ * identical in effect to n_steps calls of bgamd_env_step_greedy; between two steps of a run the apply of one and the
+ * roots of the next share a launch. */
+int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision, int64_t n_steps, void *stream);
 int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq /*[n,4,2]*/,
                           int32_t *d_seq_len, float *d_value, void *stream);
 

@@ -902,3 +902,23 @@ def test_odd_lane_counts(bg, O, weights, n):
     for _ in range(6):
         env.step_random()
     assert env.stats()["error_flags"] == 0
+
+
+def test_run_greedy_equals_repeated_steps(bg, weights):
+    """bgamd_env_run_greedy(k) plays exactly the games of k calls of step_greedy (fused step boundaries, alternating
+    counter sets, trajectory log, exploration), for the incremental and a dense value-net mode."""
+    n = 3000
+    for prec, eps in ((bg.F32, 0.0), (bg.F32, 0.15), (bg.F16X2, 0.0)):
+        a, b = bg.VecGame(n, seed=321), bg.VecGame(n, seed=321)
+        a.load_weights(weights); b.load_weights(weights)
+        ta, tb = a.record_trajectory(40), b.record_trajectory(40)
+        for k in (1, 2, 7, 16):
+            for _ in range(k):
+                a.step_greedy(precision=prec, epsilon=eps)
+            b.run_greedy(k, precision=prec, epsilon=eps)
+            assert np.array_equal(_np(a.states()), _np(b.states())) and np.array_equal(_np(a.turns()), _np(b.turns())), (prec, eps, k)
+        assert np.array_equal(_np(ta), _np(tb))
+        sa, sb = a.stats(), b.stats()
+        assert sa["error_flags"] == 0 and all(sa[q] == sb[q] for q in ("steps", "games_finished", "p1_wins", "rows_evaluated"))
+        ia, ib = _np(a.unique_rows_info()), _np(b.unique_rows_info())       # block order follows the allocation atomics
+        assert np.array_equal(ia[np.lexsort((ia[:, 1], ia[:, 0]))], ib[np.lexsort((ib[:, 1], ib[:, 0]))])
