@@ -327,13 +327,13 @@ class VecGame:
         return out
 
     # -- kernel timing (bench.py)
-    def time_kernels(self, enable=True, groups=None):
+    def time_kernels(self, enable=True, groups=None, stride=1):
         """groups: iterable of group names to bracket (default: all): enumerate_ordered, eval, apply, step_random,
         expand, leaves, root (the per-game dense pass of the incremental value net)."""
         names = ("enumerate_ordered", "eval", "apply", "step_random", "expand", "leaves", "root")
         arg = int(bool(enable))
-        if enable and groups is not None:
-            arg = sum(1 << names.index(g) for g in groups) << 8
+        if enable and (groups is not None or stride > 1):
+            arg = (sum(1 << names.index(g) for g in (groups if groups is not None else names)) << 8) | (int(stride) << 20)
         _capi.check(self._lib.bgamd_env_time_kernels(self._h, arg), "time_kernels")
 
     def kernel_times(self):

@@ -554,6 +554,8 @@ struct bgamd_env {
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
+    unsigned timing_stride = 1;            // ... on every timing_stride-th launch of the group (an event pair costs ~4 us)
+    unsigned timing_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev;            // pairs
     std::vector<int> ev_kind;
     size_t ev_used = 0;
@@ -581,6 +583,7 @@ struct KTimer {
     bgamd_env *env; hipStream_t s; size_t slot; bool on;
     KTimer(bgamd_env *e, hipStream_t st, int kind) : env(e), s(st), slot(0), on((e->timing >> kind) & 1u)
     {
+        if (on && e->timing_stride > 1) on = (e->timing_seen[kind]++ % e->timing_stride) == 0;
         if (!on) return;
         if (env->ev_used * 2 + 2 > env->ev.size()) {
             if (env->ev.size() >= 2 * 8192) { flush_events(env); }
@@ -1197,7 +1200,10 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
 {
     if (!env) return BGAMD_E_INVALID;
     if (!enable && env->timing) flush_events(env);
-    env->timing = enable == 1 ? 0xFFu : (unsigned)enable >> 8;      // 1 = every group, (mask << 8) = chosen groups
+    env->timing = enable == 1 ? 0xFFu : ((unsigned)enable >> 8) & 0xFFu;   // 1 = every group, (mask << 8) = chosen groups
+    env->timing_stride = ((unsigned)enable >> 20) & 0xFFu;                 // (stride << 20): every stride-th launch only
+    if (env->timing_stride == 0) env->timing_stride = 1;
+    for (unsigned &c : env->timing_seen) c = 0;
     return BGAMD_OK;
 }
 
