@@ -460,10 +460,12 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
 #undef BG_PUSH
         if (cnt > DELTA_MAX) cnt = DELTA_MAX;            // cannot happen for a legal turn
         n_delta += cnt;
-        uint32_t maxcnt = cnt;                             // wave-uniform trip count of the apply loops
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { const uint32_t o = __shfl_xor(maxcnt, m, 64); maxcnt = o > maxcnt ? o : maxcnt; }
-        maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+        uint32_t maxcnt = 0;                               // wave-uniform trip count of the apply loops: max over the lanes,
+#pragma unroll                                             // built bit by bit from ballots (no cross-lane data movement)
+        for (int b = 4; b >= 0; --b) {
+            const uint32_t t = maxcnt | (1u << b);
+            if (__ballot(cnt >= t) != 0ull) maxcnt = t;
+        }
         __builtin_amdgcn_wave_barrier();
 
         // ---- 32 hidden units at a time: root term (the next chunk's is in flight meanwhile), a += Δ · W1[:, f] over
