@@ -131,53 +131,33 @@ enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
 __host__ __device__ constexpr int expand_threads(int mode) { return mode == 3 ? BG_EXPAND_NT_LEAF : BG_EXPAND_NT_PLY; }
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 
-template <int MODE>
-__global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e, StagedView sv)
+// One block iteration: thread t (< n_nodes) takes node in[first + t].  Returns (block-uniform) where the children went:
+// *out_base / *out_total in the MODE's output list.  All threads of the block must call it.
+template <int MODE, int NT>
+__device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const Node *__restrict__ in,
+                                             unsigned long long first, unsigned long long n_nodes, int np,
+                                             unsigned long long *out_base, uint32_t *out_total)
 {
-    constexpr int NT = expand_threads(MODE);
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
     __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31
     __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
-    const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
-    const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
-    unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
-    if (n_in > cap_in) n_in = cap_in;
-    // nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole
-    // grid, 64 per workgroup at least
-    unsigned long long NPB = (n_in + gridDim.x - 1) / gridDim.x;
-    NPB = (NPB + 63) & ~63ull;
-    NPB = NPB < 64 ? 64 : (NPB > (unsigned long long)NT ? (unsigned long long)NT : NPB);
-    unsigned long long staged_total = 0;
-    if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&e.counters[C_FNODES], n_in);
-        atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
-    }
-    // software pipeline over block iterations: the node of the NEXT iteration is loaded at the start of this one and
-    // its game's planes are gathered once it has arrived, so neither global round trip sits on the critical path
-    Node nd_next{0u, 0u};
-    uint32_t pl_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}, meta_next = 0;
-    {
-        const unsigned long long n0 = (unsigned long long)blockIdx.x * NPB + threadIdx.x;
-        if (threadIdx.x < NPB && n0 < n_in) { nd_next = in[n0]; load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
-    }
-    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
-        const unsigned long long ni = blk * NPB + threadIdx.x;
-        const bool valid = threadIdx.x < NPB && ni < n_in;
-        const unsigned long long ni_next = threadIdx.x < NPB ? (blk + gridDim.x) * NPB + threadIdx.x : ~0ull;
-        uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
-        Node nd = nd_next;
+    const bool valid = threadIdx.x < n_nodes;
+    uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
+    Node nd{0u, 0u};
+    if (valid) {
+        nd = in[first + threadIdx.x];
+        uint32_t pl_next[8];
+        load_planes(e, (long long)nd.game, pl_next);
+        const uint32_t meta = e.meta[nd.game];
+        NodeState s;
+        uint32_t m0 = 0;
+        Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
+        node_build(nd, pl_next, meta, s, &prev_own, &prev_opp);
         {
-            NodeState s;
-            uint32_t m0 = 0;
-            int die = 1;
-            Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
-            if (valid) node_build(nd, pl_next, meta_next, s, &prev_own, &prev_opp);
-            if (ni_next < n_in) nd_next = in[ni_next];          // arrives during the successor phase below
-            if (valid) {
-                die = (s.len & 1) ? s.dB : s.dA;
-                if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
+            const int die = (s.len & 1) ? s.dB : s.dA;
+            if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
                 bool pruned_all = false;
                 if (MODE == MODE_LEAF && !s.dbl && s.len == 1 && key_pass(nd.key) && m0) {
                     // Non-doubles, second die order: this node is "x with d2", its successors are "then y with d1".
@@ -236,61 +216,117 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
                 s_par_mask[threadIdx.x] = m0;
                 s_par_game[threadIdx.x] = nd.game;
                 s_par_key[threadIdx.x] = nd.key | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
-            }
         }
-        uint32_t total, totB = 0;
-        const uint32_t off = block_scan_256<NW, true>(cnt, &total, s_wave);
-        s_par_off[threadIdx.x] = off;
+    }
+    uint32_t total, totB = 0;
+    const uint32_t off = block_scan_256<NW, true>(cnt, &total, s_wave);
+    s_par_off[threadIdx.x] = off;
+    unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
+    const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
+    const unsigned long long baseA = block_alloc<false>(topA, total, &s_slot);      // the scan just synchronised
+    bool ok = baseA + total <= capA;
+    if (MODE == MODE_PLY2) {                               // stuck doubles nodes are leaf parents as they are
+        const uint32_t offB = block_scan_256<NW, true>(cntB, &totB, s_wave);
+        const unsigned long long baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
+        ok = ok && baseB + totB <= (unsigned long long)sv.cap_f;
+        if (ok && cntB) sv.f[baseB + offB] = Node{nd.game, nd.key};
+    }
+    if (!ok) flag_overflow(e);
+    __syncthreads();                                       // parent records and offsets are in place
+    if (ok) {
+        for (uint32_t q = threadIdx.x; q < total; q += NT) {
+            int lo = 0, hi = np - 1;                       // last parent whose offset is <= q
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_par_off[mid] <= q) lo = mid; else hi = mid - 1;
+            }
+            const int par = lo;
+            uint32_t rank = q - s_par_off[par];
+            uint32_t m = s_par_mask[par];
+            const uint32_t pk = s_par_key[par];
+            const int pl = (int)(pk >> 31), die = (int)((pk >> 27) & 7u);
+            Side a{{s_par_plane[0][par], s_par_plane[1][par], s_par_plane[2][par], s_par_plane[3][par]}};
+            Side b{{s_par_plane[4][par], s_par_plane[5][par], s_par_plane[6][par], s_par_plane[7][par]}};
+            uint32_t key = pk & KEY_MASK;
+            if (m) {
+                while (rank--) m &= m - 1;
+                const int o = __ffs(m) - 1;
+                apply_move(a, b, pl, o, die);
+                key = key_child(key, o);
+            }
+            const uint32_t game = s_par_game[par];
+            const unsigned long long d = baseA + q;
+            if (MODE == MODE_LEAF) {
+                const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
+                sv.u_rows[2 * d] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
+                sv.u_rows[2 * d + 1] = make_uint4(s2.b[0], s2.b[1], s2.b[2], s2.b[3]);
+                sv.u_info[d] = make_uint2(game, key | (pl ? 0x80000000u : 0u));
+            } else if (MODE == MODE_PLY2) sv.d2[d] = Node{game, key};
+            else sv.f[d] = Node{game, key};
+        }
+    }
+    __syncthreads();                                       // the records are reused by the next phase; its reads of what
+    *out_base = baseA;                                     // this one wrote to global memory come after this barrier
+    *out_total = ok ? total : 0u;
+}
+
+// nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole grid,
+// 64 per workgroup at least
+__device__ __forceinline__ unsigned long long nodes_per_block(unsigned long long n_in, int nt)
+{
+    unsigned long long npb = (n_in + gridDim.x - 1) / gridDim.x;
+    npb = (npb + 63) & ~63ull;
+    return npb < 64 ? 64 : (npb > (unsigned long long)nt ? (unsigned long long)nt : npb);
+}
+
+// leaf stage (and a single doubles ply, kept for tests and experiments)
+template <int MODE>
+__global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e, StagedView sv)
+{
+    constexpr int NT = expand_threads(MODE);
+    const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
+    const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
+    unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
+    if (n_in > cap_in) n_in = cap_in;
+    const unsigned long long NPB = nodes_per_block(n_in, NT);
+    unsigned long long staged_total = 0;
+    if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&e.counters[C_FNODES], n_in);
+        atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
+    }
+    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+        const unsigned long long first = blk * NPB;
+        const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
+        unsigned long long base;
+        uint32_t total;
+        expand_phase<MODE, NT>(e, sv, in, first, cnt, (int)NPB, &base, &total);
         staged_total += total;
-        unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
-        const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
-        const unsigned long long baseA = block_alloc<false>(topA, total, &s_slot);      // the scan just synchronised
-        bool ok = baseA + total <= capA;
-        if (MODE == MODE_PLY2) {                               // stuck doubles nodes are leaf parents as they are
-            const uint32_t offB = block_scan_256<NW, true>(cntB, &totB, s_wave);
-            const unsigned long long baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
-            ok = ok && baseB + totB <= (unsigned long long)sv.cap_f;
-            if (ok && cntB) sv.f[baseB + offB] = Node{nd.game, nd.key};
-        }
-        if (!ok) flag_overflow(e);
-        __syncthreads();                                       // parent records and offsets are in place
-        if (ok) {
-            const int np = (int)NPB;
-            for (uint32_t q = threadIdx.x; q < total; q += NT) {
-                int lo = 0, hi = np - 1;                       // last parent whose offset is <= q
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (s_par_off[mid] <= q) lo = mid; else hi = mid - 1;
-                }
-                const int par = lo;
-                uint32_t rank = q - s_par_off[par];
-                uint32_t m = s_par_mask[par];
-                const uint32_t pk = s_par_key[par];
-                const int pl = (int)(pk >> 31), die = (int)((pk >> 27) & 7u);
-                Side a{{s_par_plane[0][par], s_par_plane[1][par], s_par_plane[2][par], s_par_plane[3][par]}};
-                Side b{{s_par_plane[4][par], s_par_plane[5][par], s_par_plane[6][par], s_par_plane[7][par]}};
-                uint32_t key = pk & KEY_MASK;
-                if (m) {
-                    while (rank--) m &= m - 1;
-                    const int o = __ffs(m) - 1;
-                    apply_move(a, b, pl, o, die);
-                    key = key_child(key, o);
-                }
-                const uint32_t game = s_par_game[par];
-                const unsigned long long d = baseA + q;
-                if (MODE == MODE_LEAF) {
-                    const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
-                    sv.u_rows[2 * d] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
-                    sv.u_rows[2 * d + 1] = make_uint4(s2.b[0], s2.b[1], s2.b[2], s2.b[3]);
-                    sv.u_info[d] = make_uint2(game, key | (pl ? 0x80000000u : 0u));
-                } else if (MODE == MODE_PLY2) sv.d2[d] = Node{game, key};
-                else sv.f[d] = Node{game, key};
-            }
-        }
-        if (ni_next < n_in) { load_planes(e, (long long)nd_next.game, pl_next); meta_next = e.meta[nd_next.game]; }
-        __syncthreads();                                       // the records are reused by the next iteration
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
+}
+
+// the doubles turns' plies 2 AND 3 in one launch: a workgroup expands its share of the ply-1 nodes and goes straight on
+// with the ply-2 nodes it just wrote (one contiguous allocation), so the second ply costs neither a launch nor a
+// trip through the list counter
+__global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvView e, StagedView sv)
+{
+    constexpr int NT = expand_threads(MODE_PLY2);
+    unsigned long long n_in = sv.tops[T_D1];
+    if (n_in > (unsigned long long)sv.cap_d1) n_in = (unsigned long long)sv.cap_d1;
+    const unsigned long long NPB = nodes_per_block(n_in, NT / 4);
+    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+        const unsigned long long first = blk * NPB;
+        const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
+        unsigned long long base2;
+        uint32_t total2;
+        expand_phase<MODE_PLY2, NT>(e, sv, sv.d1, first, cnt, (int)NPB, &base2, &total2);
+        for (uint32_t c = 0; c < total2; c += NT) {
+            const unsigned long long n3 = total2 - c < (uint32_t)NT ? total2 - c : (uint32_t)NT;
+            unsigned long long base3;
+            uint32_t total3;
+            expand_phase<MODE_PLY3, NT>(e, sv, sv.d2, base2 + c, n3, NT, &base3, &total3);
+        }
+    }
 }
 
 // finds the reference-order index of a given sequence and the list length (BGAMD_WANT_INDEX)

@@ -1024,8 +1024,7 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
         }
         {
             KTimer t(env, s, 4);
-            hipLaunchKernelGGL(expand_kernel<MODE_PLY2>, egrid(n * 3, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
-            hipLaunchKernelGGL(expand_kernel<MODE_PLY3>, egrid(n * 6, MODE_PLY3), dim3(expand_threads(MODE_PLY3)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
         }
         {
             KTimer t(env, s, 5);
