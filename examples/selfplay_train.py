@@ -5,6 +5,9 @@ win rate against a uniformly random mover before and after, and against the refe
 Not the reference's training CLI (out of scope) -- a 60-line demonstration that the pieces compose.
 
     python examples/selfplay_train.py --games 512 --rounds 120
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/selfplay_train.py --games 4096
+        (config 4/5 shape: every rank plays its own shard of games, ONE all-reduce of the 25 601-float update per
+         training step keeps the replicas' weights identical; --dist-backend gloo lets ranks share a GPU for a rehearsal)
 """
 import argparse
 import os
@@ -38,32 +41,54 @@ def main():
     ap.add_argument("--rounds", type=int, default=120)
     ap.add_argument("--eps", type=float, default=0.05)
     ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
+    ap.add_argument("--dist-backend", default="nccl")
     a = ap.parse_args()
-    env, arena = bg.VecGame(a.games, seed=1), bg.VecGame(1024, seed=2)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        from backgammon_env.shard import shard_for_rank
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(local if a.dist_backend == "nccl" else local % torch.cuda.device_count())
+        dist.init_process_group(a.dist_backend)
+        group = dist.group.WORLD
+        off, stride = shard_for_rank(rank, world, a.games)
+        env = bg.VecGame(a.games, seed=1, lane_offset=off, lane_stride=stride)
+    else:
+        env = bg.VecGame(a.games, seed=1)
+    arena = bg.VecGame(1024, seed=2)
+    say = print if rank == 0 else (lambda *x, **k: None)
     if a.host_learner:
         L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
     else:
         L = DeviceTDLambdaLearner(xavier_init(), max_games=a.games, alpha=0.1, lam=0.7)
-    print("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
+    say("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
     t0, turns = time.time(), 0
     for r in range(a.rounds):
-        L.update_learning_params(r * a.games)
+        L.update_learning_params(r * a.games * world)
         env.load_weights(L.theta.cpu().numpy())
         rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=a.eps)
-        scale = min(1.0, 24.0 / a.games)
+        scale = min(1.0, 24.0 / (a.games * world))
         if a.host_learner:
-            sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, batch_scale=scale)
+            sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, group=group, batch_scale=scale)
         else:
-            sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=scale)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale)
         turns += cnt
         if r % 20 == 19:
-            print(f"round {r + 1}: {(r + 1) * a.games} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
-                  f"{turns / (time.time() - t0):.0f} turns/s", flush=True)
+            say(f"round {r + 1}: {(r + 1) * a.games * world} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
+                f"{world * turns / (time.time() - t0):.0f} turns/s", flush=True)
     w_after = L.theta.cpu().numpy()
-    print("after: vs random", head_to_head(arena, w_after, None), flush=True)
+    if world > 1:                                             # the replicas must still hold the same weights
+        chk = torch.tensor([float(np.abs(w_after).sum()), -float(np.abs(w_after).sum())], dtype=torch.float64, device="cuda")
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=group)
+        assert chk[0].item() == -chk[1].item(), "replicas diverged"
+        say("replicas identical across", world, "ranks")
+    say("after: vs random", head_to_head(arena, w_after, None), flush=True)
     ref = os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32")       # the reference's own 100k-episode checkpoint
     if os.path.exists(ref):
-        print("after: vs tdgammonNEW100k", head_to_head(arena, w_after, np.fromfile(ref, dtype=np.float32)), flush=True)
+        say("after: vs tdgammonNEW100k", head_to_head(arena, w_after, np.fromfile(ref, dtype=np.float32)), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
