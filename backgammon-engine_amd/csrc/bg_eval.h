@@ -504,12 +504,25 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
+        {
+            // per-game arg-max (P1) / arg-min (P2), smallest reference key wins ties: (ordered value bits, ~key) packed in
+            // 64 bits.  The rows of a game sit in neighbouring lanes, so the maximum is first taken over each run of
+            // equal games inside the wave and only the run's first lane goes to memory -- ~4 atomics per wave instead
+            // of 64 mostly same-address ones.
             const float v = fast_sigmoid(sum + b2);
-            values[row] = v;
+            if (valid) values[row] = v;
             uint32_t bits = __float_as_uint(v);
             bits = (inf.y >> 31) ? ~bits : bits;
-            atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
+            unsigned long long pack = valid ? (((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu)) : 0ull;
+            const uint32_t game = valid ? inf.x : 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t og = __shfl_down(game, d, 64);
+                const unsigned long long op = __shfl_down(pack, d, 64);
+                if (lane + d < 64 && og == game && op > pack) pack = op;
+            }
+            const uint32_t pg = __shfl_up(game, 1, 64);
+            if (valid && (lane == 0 || pg != game)) atomicMax(&best[game], pack);
         }
         tile = next_tile;
     }
