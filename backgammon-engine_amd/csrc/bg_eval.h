@@ -30,6 +30,28 @@ __device__ __forceinline__ float fast_sigmoid(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 
+// Per-game arg-max (P1) / arg-min (P2) with "smallest reference key wins ties" (model.py:212-213): one 64-bit
+// atomicMax of (ordered value bits, ~key) per game.  The rows of a game sit in neighbouring lanes, so the maximum is
+// first taken over each run of equal games among the first `width` lanes and only the run's first lane goes to memory
+// (a few atomics per wave instead of one per row, most of them on the same address).  All 64 lanes must call it.
+__device__ __forceinline__ void best_atomic_max(unsigned long long *__restrict__ best, uint32_t game, float v, uint32_t key_turn,
+                                                bool valid, int width)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t bits = __float_as_uint(v);
+    bits = (key_turn >> 31) ? ~bits : bits;
+    unsigned long long pack = valid ? (((unsigned long long)bits << 32) | (uint32_t)~(key_turn & 0x7FFFFFFFu)) : 0ull;
+    if (!valid) game = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t og = __shfl_down(game, d, 64);
+        const unsigned long long op = __shfl_down(pack, d, 64);
+        if (d < width && lane + d < width && og == game && op > pack) pack = op;
+    }
+    const uint32_t pg = __shfl_up(game, 1, 64);
+    if (valid && (lane == 0 || pg != game)) atomicMax(&best[game], pack);
+}
+
 // per-row decode state: for each side q (0 = PLAYER1, 1 = PLAYER2)
 //   ev[q]   : mask whose bit (i+1) is this lane's EVEN-step feature of point i  (n>=1 | n>=2)
 //   od[q][k]: planes of the odd-step code; feature value = 0.5 * code            (n>=3 | (n-3)/2)
@@ -235,19 +257,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
         for (int c = 0; c < 16; ++c) sum += sRed[(16 * h + c) * EVAL_RED_STRIDE + r];
         sum += __shfl_xor(sum, 32, 64);
         __builtin_amdgcn_wave_barrier();
-        if (h == 0) {
+        {   // lanes 0..31 (h == 0) hold the 32 rows of the tile
             const long long orow = tile * 32 + r;
-            if (orow < n_rows) {
-                const float v = fast_sigmoid(sum + b2);
-                values[orow] = v;
-                if (info) {
-                    // per-game arg-max (P1) / arg-min (P2) with "smallest reference key wins ties":
-                    // one 64-bit atomicMax of (ordered value bits, ~key)      (model.py:212-213)
-                    const uint2 inf = info[orow];
-                    uint32_t bits = __float_as_uint(v);
-                    bits = (inf.y >> 31) ? ~bits : bits;
-                    atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
-                }
+            const bool vrow = h == 0 && orow < n_rows;
+            const float v = fast_sigmoid(sum + b2);
+            if (vrow) values[orow] = v;
+            if (info) {                                        // wave-uniform
+                const uint2 inf = vrow ? info[orow] : make_uint2(0u, 0u);
+                best_atomic_max(best, inf.x, v, inf.y, vrow, 32);
             }
         }
     }
@@ -505,24 +522,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         }
         __builtin_amdgcn_wave_barrier();
         {
-            // per-game arg-max (P1) / arg-min (P2), smallest reference key wins ties: (ordered value bits, ~key) packed in
-            // 64 bits.  The rows of a game sit in neighbouring lanes, so the maximum is first taken over each run of
-            // equal games inside the wave and only the run's first lane goes to memory -- ~4 atomics per wave instead
-            // of 64 mostly same-address ones.
             const float v = fast_sigmoid(sum + b2);
             if (valid) values[row] = v;
-            uint32_t bits = __float_as_uint(v);
-            bits = (inf.y >> 31) ? ~bits : bits;
-            unsigned long long pack = valid ? (((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu)) : 0ull;
-            const uint32_t game = valid ? inf.x : 0xFFFFFFFFu;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t og = __shfl_down(game, d, 64);
-                const unsigned long long op = __shfl_down(pack, d, 64);
-                if (lane + d < 64 && og == game && op > pack) pack = op;
-            }
-            const uint32_t pg = __shfl_up(game, 1, 64);
-            if (valid && (lane == 0 || pg != game)) atomicMax(&best[game], pack);
+            best_atomic_max(best, inf.x, v, inf.y, valid, 64);
         }
         tile = next_tile;
     }
@@ -665,17 +667,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_bf16_kernel(
         for (int c = 0; c < 16; ++c) sum += sRed[(16 * h + c) * EVAL_RED_STRIDE + r];
         sum += __shfl_xor(sum, 32, 64);
         __builtin_amdgcn_wave_barrier();
-        if (h == 0) {
+        {   // lanes 0..31 (h == 0) hold the 32 rows of the tile
             const long long orow = tile * 32 + r;
-            if (orow < n_rows) {
-                const float v = fast_sigmoid(sum + b2);
-                values[orow] = v;
-                if (info) {
-                    const uint2 inf = info[orow];
-                    uint32_t bits = __float_as_uint(v);
-                    bits = (inf.y >> 31) ? ~bits : bits;
-                    atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
-                }
+            const bool vrow = h == 0 && orow < n_rows;
+            const float v = fast_sigmoid(sum + b2);
+            if (vrow) values[orow] = v;
+            if (info) {                                        // wave-uniform
+                const uint2 inf = vrow ? info[orow] : make_uint2(0u, 0u);
+                best_atomic_max(best, inf.x, v, inf.y, vrow, 32);
             }
         }
     }
@@ -944,17 +943,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f16x2_kernel(
         for (int c = 0; c < 16; ++c) sum += sRed[(16 * h + c) * EVAL_RED_STRIDE + r];
         sum += __shfl_xor(sum, 32, 64);
         __builtin_amdgcn_wave_barrier();
-        if (h == 0) {
+        {   // lanes 0..31 (h == 0) hold the 32 rows of the tile
             const long long orow = tile * 32 + r;
-            if (orow < n_rows) {
-                const float v = fast_sigmoid(sum + b2);
-                values[orow] = v;
-                if (info) {
-                    const uint2 inf = info[orow];
-                    uint32_t bits = __float_as_uint(v);
-                    bits = (inf.y >> 31) ? ~bits : bits;
-                    atomicMax(&best[inf.x], ((unsigned long long)bits << 32) | (uint32_t)~(inf.y & 0x7FFFFFFFu));
-                }
+            const bool vrow = h == 0 && orow < n_rows;
+            const float v = fast_sigmoid(sum + b2);
+            if (vrow) values[orow] = v;
+            if (info) {                                        // wave-uniform
+                const uint2 inf = vrow ? info[orow] : make_uint2(0u, 0u);
+                best_atomic_max(best, inf.x, v, inf.y, vrow, 32);
             }
         }
     }
