@@ -131,23 +131,23 @@ enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
 __host__ __device__ constexpr int expand_threads(int mode) { return mode == 3 ? BG_EXPAND_NT_LEAF : BG_EXPAND_NT_PLY; }
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 
-// One block iteration: thread t (< n_nodes) takes node in[first + t].  Returns (block-uniform) where the children went:
-// *out_base / *out_total in the MODE's output list.  All threads of the block must call it.
+// One block iteration: every thread takes node in[node_idx] (node_idx < 0: none; threads >= np never have one).  Returns
+// (block-uniform) where the children went: *out_base / *out_total in the MODE's output list.  All threads of the block
+// must call it.
 template <int MODE, int NT>
 __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const Node *__restrict__ in,
-                                             unsigned long long first, unsigned long long n_nodes, int np,
-                                             unsigned long long *out_base, uint32_t *out_total)
+                                             long long node_idx, int np, unsigned long long *out_base, uint32_t *out_total)
 {
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
     __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31
     __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
-    const bool valid = threadIdx.x < n_nodes;
+    const bool valid = node_idx >= 0;
     uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
     Node nd{0u, 0u};
     if (valid) {
-        nd = in[first + threadIdx.x];
+        nd = in[node_idx];
         uint32_t pl_next[8];
         load_planes(e, (long long)nd.game, pl_next);
         const uint32_t meta = e.meta[nd.game];
@@ -288,18 +288,22 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
     const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
     unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
     if (n_in > cap_in) n_in = cap_in;
-    const unsigned long long NPB = nodes_per_block(n_in, NT);
     unsigned long long staged_total = 0;
     if (MODE == MODE_LEAF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
-    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
-        const unsigned long long first = blk * NPB;
-        const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
+    // 64-node chunks are dealt to the waves round-robin over the whole grid: the list holds the non-doubles leaf
+    // parents first and the doubles ones (three times the successors) at the end, and contiguous shares left the last
+    // workgroups with all the heavy nodes
+    const unsigned long long n_chunks = (n_in + 63) >> 6;
+    const unsigned int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (unsigned long long it = 0; it * (NT / 64) * gridDim.x < n_chunks; ++it) {
+        const unsigned long long chunk = (it * (NT / 64) + wv) * gridDim.x + blockIdx.x;
+        const unsigned long long node = chunk * 64 + lane;
         unsigned long long base;
         uint32_t total;
-        expand_phase<MODE, NT>(e, sv, in, first, cnt, (int)NPB, &base, &total);
+        expand_phase<MODE, NT>(e, sv, in, node < n_in ? (long long)node : -1ll, NT, &base, &total);
         staged_total += total;
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
@@ -319,12 +323,12 @@ __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvV
         const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
         unsigned long long base2;
         uint32_t total2;
-        expand_phase<MODE_PLY2, NT>(e, sv, sv.d1, first, cnt, (int)NPB, &base2, &total2);
+        expand_phase<MODE_PLY2, NT>(e, sv, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, (int)NPB, &base2, &total2);
         for (uint32_t c = 0; c < total2; c += NT) {
             const unsigned long long n3 = total2 - c < (uint32_t)NT ? total2 - c : (uint32_t)NT;
             unsigned long long base3;
             uint32_t total3;
-            expand_phase<MODE_PLY3, NT>(e, sv, sv.d2, base2 + c, n3, NT, &base3, &total3);
+            expand_phase<MODE_PLY3, NT>(e, sv, sv.d2, threadIdx.x < n3 ? (long long)(base2 + c + threadIdx.x) : -1ll, NT, &base3, &total3);
         }
     }
 }
