@@ -387,11 +387,13 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     const int lane = threadIdx.x & 63;
     // A tile's cost follows its longest delta list (a doubles turn costs twice a plain one), so the 64-row tiles of a
     // workgroup's contiguous range go to whichever wave is free (LDS ticket) instead of a fixed stride per wave
-    const long long t_lo = n_tiles * blockIdx.x / gridDim.x, t_hi = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    // (tiles of a workgroup: b, b + G, b + 2G, ... -- the arena holds runs of light rows (non-doubles turns) and runs of
+    // heavy ones (doubles), a strided share gives every workgroup the same mix while each tile stays homogeneous)
+    const long long t_hi = n_tiles;
     auto grab = [&]() -> long long {
         unsigned int t = 0;
         if (lane == 0) t = atomicAdd(&s_ticket, 1u);
-        return t_lo + (long long)__builtin_amdgcn_readfirstlane(t);
+        return (long long)blockIdx.x + (long long)__builtin_amdgcn_readfirstlane(t) * (long long)gridDim.x;
     };
     const float b2 = *b2p;
     constexpr float NL2E = -1.44269504088896340736f;

@@ -293,17 +293,14 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
         atomicAdd(&e.counters[C_FNODES], n_in);
         atomicAdd(&e.counters[C_DNODES], sv.tops[T_D1] + sv.tops[T_D2]);
     }
-    // 64-node chunks are dealt to the waves round-robin over the whole grid: the list holds the non-doubles leaf
-    // parents first and the doubles ones (three times the successors) at the end, and contiguous shares left the last
-    // workgroups with all the heavy nodes
-    const unsigned long long n_chunks = (n_in + 63) >> 6;
-    const unsigned int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (unsigned long long it = 0; it * (NT / 64) * gridDim.x < n_chunks; ++it) {
-        const unsigned long long chunk = (it * (NT / 64) + wv) * gridDim.x + blockIdx.x;
-        const unsigned long long node = chunk * 64 + lane;
+    // contiguous shares: a workgroup's nodes are all of one kind (the list holds the non-doubles leaf parents first, the
+    // doubles ones at the end), so its rows form tiles of similar delta-list lengths for the value net
+    const unsigned long long NPB = nodes_per_block(n_in, NT);
+    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+        const unsigned long long node = blk * NPB + threadIdx.x;
         unsigned long long base;
         uint32_t total;
-        expand_phase<MODE, NT>(e, sv, in, node < n_in ? (long long)node : -1ll, NT, &base, &total);
+        expand_phase<MODE, NT>(e, sv, in, (threadIdx.x < NPB && node < n_in) ? (long long)node : -1ll, (int)NPB, &base, &total);
         staged_total += total;
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
