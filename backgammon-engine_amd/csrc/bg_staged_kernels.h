@@ -131,26 +131,38 @@ enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
 __host__ __device__ constexpr int expand_threads(int mode) { return mode == 3 ? BG_EXPAND_NT_LEAF : BG_EXPAND_NT_PLY; }
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;    // pass | origins | len
 
-// One block iteration: every thread takes node in[node_idx] (node_idx < 0: none; threads >= np never have one).  Returns
-// (block-uniform) where the children went: *out_base / *out_total in the MODE's output list.  All threads of the block
-// must call it.
+// a thread's node with its game's planes and meta word, loaded ahead of use
+struct NodeIn { Node nd; uint32_t pl[8]; uint32_t meta; bool valid; };
+__device__ __forceinline__ void node_fetch(const EnvView &e, const Node *__restrict__ in, long long node_idx, NodeIn &x)
+{
+    x.valid = node_idx >= 0;
+    x.nd = Node{0u, 0u}; x.meta = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x.pl[k] = 0;
+    if (x.valid) {
+        x.nd = in[node_idx];
+        load_planes(e, (long long)x.nd.game, x.pl);
+        x.meta = e.meta[x.nd.game];
+    }
+}
+
+// One block iteration: every thread brings its node (threads >= np never have one).  Returns (block-uniform) where the
+// children went: *out_base / *out_total in the MODE's output list.  All threads of the block must call it.
 template <int MODE, int NT>
-__device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const Node *__restrict__ in,
-                                             long long node_idx, int np, unsigned long long *out_base, uint32_t *out_total)
+__device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const NodeIn &x, int np,
+                                             unsigned long long *out_base, uint32_t *out_total)
 {
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
     __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31
     __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
-    const bool valid = node_idx >= 0;
+    const bool valid = x.valid;
     uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
-    Node nd{0u, 0u};
+    const Node nd = x.nd;
     if (valid) {
-        nd = in[node_idx];
-        uint32_t pl_next[8];
-        load_planes(e, (long long)nd.game, pl_next);
-        const uint32_t meta = e.meta[nd.game];
+        const uint32_t (&pl_next)[8] = x.pl;
+        const uint32_t meta = x.meta;
         NodeState s;
         uint32_t m0 = 0;
         Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
@@ -296,12 +308,22 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
     // contiguous shares: a workgroup's nodes are all of one kind (the list holds the non-doubles leaf parents first, the
     // doubles ones at the end), so its rows form tiles of similar delta-list lengths for the value net
     const unsigned long long NPB = nodes_per_block(n_in, NT);
-    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+    auto idx_of = [&](unsigned long long blk) -> long long {
         const unsigned long long node = blk * NPB + threadIdx.x;
+        return (threadIdx.x < NPB && node < n_in) ? (long long)node : -1ll;
+    };
+    // software pipeline over block iterations: the next iteration's node, planes and meta are in flight while this
+    // iteration scans, allocates and writes its successors
+    NodeIn cur, nxt;
+    node_fetch(e, in, blockIdx.x * NPB < n_in ? idx_of(blockIdx.x) : -1ll, cur);
+    for (unsigned long long blk = blockIdx.x; blk * NPB < n_in; blk += gridDim.x) {
+        const unsigned long long nb = blk + gridDim.x;
+        node_fetch(e, in, nb * NPB < n_in ? idx_of(nb) : -1ll, nxt);
         unsigned long long base;
         uint32_t total;
-        expand_phase<MODE, NT>(e, sv, in, (threadIdx.x < NPB && node < n_in) ? (long long)node : -1ll, (int)NPB, &base, &total);
+        expand_phase<MODE, NT>(e, sv, cur, (int)NPB, &base, &total);
         staged_total += total;
+        cur = nxt;
     }
     if (MODE == MODE_LEAF && threadIdx.x == 0 && staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
 }
@@ -320,12 +342,16 @@ __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvV
         const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
         unsigned long long base2;
         uint32_t total2;
-        expand_phase<MODE_PLY2, NT>(e, sv, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, (int)NPB, &base2, &total2);
+        NodeIn x2;
+        node_fetch(e, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
+        expand_phase<MODE_PLY2, NT>(e, sv, x2, (int)NPB, &base2, &total2);
         for (uint32_t c = 0; c < total2; c += NT) {
             const unsigned long long n3 = total2 - c < (uint32_t)NT ? total2 - c : (uint32_t)NT;
             unsigned long long base3;
             uint32_t total3;
-            expand_phase<MODE_PLY3, NT>(e, sv, sv.d2, threadIdx.x < n3 ? (long long)(base2 + c + threadIdx.x) : -1ll, NT, &base3, &total3);
+            NodeIn x3;
+            node_fetch(e, sv.d2, threadIdx.x < n3 ? (long long)(base2 + c + threadIdx.x) : -1ll, x3);
+            expand_phase<MODE_PLY3, NT>(e, sv, x3, NT, &base3, &total3);
         }
     }
 }

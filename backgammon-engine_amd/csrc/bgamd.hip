@@ -980,7 +980,9 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
     auto egrid = [&](long long max_items, int mode) {    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
         const int nt = expand_threads(mode);
         long long b = (max_items + nt - 1) / nt;
-        const long long lim = (long long)env->n_cu * (2048 / nt);
+        // one workgroup per CU for the 1 024-thread leaf stage (82 VGPRs: that is what fits; a second round of workgroups
+        // would start its latency chain from scratch, a second iteration of the same workgroup has its nodes prefetched)
+        const long long lim = (long long)env->n_cu * (nt >= 1024 ? 1 : 2048 / nt);
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
     };
     const bool incremental = precision == BGAMD_F32;
