@@ -43,9 +43,16 @@ __device__ __forceinline__ void flag_overflow(const EnvView &e)
 }
 
 // ---- ply 1: lane per game -----------------------------------------------------------------------
+// lane-per-game kernels of the step boundary: threads per workgroup (measured 64 .. 1 024: 256 and 512 tie, smaller is
+// slower -- every workgroup pays two allocation atomics in the roots)
+#ifndef BG_LANE_NT
+#define BG_LANE_NT 256
+#endif
+constexpr int LANE_NT = BG_LANE_NT;
+
 __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g)
 {
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[LANE_NT / 64];
     __shared__ unsigned long long s_slot;
     LaneCtx c;
     lane_begin(e, g, flags, c);
@@ -62,8 +69,8 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
     const uint32_t nF = !c.live ? 0u : (dbl ? (ma == 0 ? 1u : 0u) : (uint32_t)(__popc(ma) + __popc(mb)));
     const uint32_t nD = (c.live && dbl) ? (uint32_t)__popc(ma) : 0u;
     uint32_t totF, totD;
-    uint32_t offF = block_scan_256(nF, &totF, s_wave);
-    uint32_t offD = block_scan_256(nD, &totD, s_wave);
+    uint32_t offF = block_scan_256<LANE_NT / 64>(nF, &totF, s_wave);
+    uint32_t offD = block_scan_256<LANE_NT / 64>(nD, &totD, s_wave);
     const unsigned long long baseF = block_alloc(&sv.tops[T_F], totF, &s_slot);
     const unsigned long long baseD = block_alloc(&sv.tops[T_D1], totD, &s_slot);
     const bool okF = baseF + totF <= (unsigned long long)sv.cap_f, okD = baseD + totD <= (unsigned long long)sv.cap_d1;
@@ -96,9 +103,9 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
     }
 }
 
-__global__ __launch_bounds__(256) void roots_kernel(EnvView e, StagedView sv, int flags)
+__global__ __launch_bounds__(LANE_NT) void roots_kernel(EnvView e, StagedView sv, int flags)
 {
-    roots_body(e, sv, flags, (long long)blockIdx.x * 256 + threadIdx.x);
+    roots_body(e, sv, flags, (long long)blockIdx.x * LANE_NT + threadIdx.x);
 }
 
 // ---- one ply per launch ---------------------------------------------------------------------------------------
@@ -422,18 +429,18 @@ __device__ __forceinline__ void apply_body(const EnvView &e, const StagedView &s
     finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
 }
 
-__global__ __launch_bounds__(256) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
+__global__ __launch_bounds__(LANE_NT) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
 {
-    apply_body(e, sv, xv, flags, epsilon, (long long)blockIdx.x * 256 + threadIdx.x);
+    apply_body(e, sv, xv, flags, epsilon, (long long)blockIdx.x * LANE_NT + threadIdx.x);
 }
 
 // Step boundary of a multi-step run: the apply of step t and the roots of step t+1 for the same lane in one launch
 // (the lane's new position is read back by the thread that just stored it).  sv_next carries the other set of list
 // counters: the value-net kernel of step t cleared it while nothing was using it.
-__global__ __launch_bounds__(256) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
-                                                       float epsilon)
+__global__ __launch_bounds__(LANE_NT) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
+                                                           float epsilon)
 {
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long g = (long long)blockIdx.x * LANE_NT + threadIdx.x;
     apply_body(e, sv, xv, flags, epsilon, g);
     __syncthreads();                                    // finish_turn's statistics scratch is free again
     roots_body(e, sv_next, flags, g);

@@ -995,7 +995,7 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
     sv.tops = env->tops_base;
     {
         KTimer t(env, s, 4);
-        hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
+        hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
     }
     for (int64_t step = 0; step < n_steps; ++step) {
         if (incremental) {
@@ -1063,16 +1063,16 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
         {
             KTimer t(env, s, 2);
             if (fused)
-                hipLaunchKernelGGL(boundary_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, sv_next, xv, flags, epsilon);
+                hipLaunchKernelGGL(boundary_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, sv_next, xv, flags, epsilon);
             else
-                hipLaunchKernelGGL(apply_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, xv, flags, epsilon);
+                hipLaunchKernelGGL(apply_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, xv, flags, epsilon);
         }
         env->sv.tops = sv.tops;                                // the set whose T_U describes the last evaluated rows
         if (fused) { parity ^= 1; sv = sv_next; }
         else if (more) {                                       // dense value-net modes: plain per-step sequence
             HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
             KTimer t(env, s, 4);
-            hipLaunchKernelGGL(roots_kernel, grid1(n, 256), dim3(256), 0, s, env->v, sv, flags);
+            hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
         }
     }
     HIPCHK(hipGetLastError());
