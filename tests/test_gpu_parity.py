@@ -883,6 +883,55 @@ def test_staged_rows_cover_every_distinct_afterstate(bg, O, weights):
     assert distinct_total > 20000 and rows_total < 1.25 * distinct_total
 
 
+def test_staged_rows_on_edge_boards_and_late_game(bg, O, weights, golden_dir):
+    """The same coverage check where the commuting-moves rules are most delicate: the reference's hand-built edge
+    boards (bear-off overrun asymmetry, bar entry, stuck positions, mid-sequence wins; fixture G1: the afterstates are the
+    reference's own) and the bear-off phase of self-play games."""
+    g = np.load(os.path.join(golden_dir, "g1_edge_calls.npz"))
+    inp, off = g["inputs"].astype(np.int32), g["off"]
+    n = len(inp)
+    env = bg.VecGame(n, arena_rows=1 << 20)
+    env.load_weights(weights)
+    env.set_states(inp[:, :28], inp[:, 28])
+    env.set_dice(inp[:, 29:31])
+    env.step_greedy(roll=False, auto_reset=False)
+    info = _np(env.unique_rows_info())
+    by_game = {}
+    for gm, k in info:
+        by_game.setdefault(int(gm), []).append(int(k))
+    for i in range(n):
+        turn, d1, d2 = int(inp[i, 28]), int(inp[i, 29]), int(inp[i, 30])
+        want = {tuple(int(v) for v in c) for c in g["states"][off[i]:off[i + 1]]}
+        got = {_replay_key(O, inp[i, :28], turn, d1, d2, k & 0x7FFFFFFF) for k in by_game.get(i, [])}
+        assert got == want, (str(g["names"][i]), len(got), len(want))
+    # late game: bear-off
+    n2 = 512
+    env = bg.VecGame(n2, seed=4242)
+    env.load_weights(weights)
+    checked = 0
+    for ply in range(120):
+        pre, pt = _np(env.states()), _np(env.turns())
+        live = (_np(env.flags()) & 4) == 0
+        env.step_greedy(auto_reset=False)
+        if ply < 60 or ply % 6:
+            continue
+        dice = _np(env.dice())
+        info = _np(env.unique_rows_info())
+        by_game = {}
+        for gm, k in info:
+            by_game.setdefault(int(gm), []).append(int(k))
+        for lane in range(0, n2, 2):
+            if not live[lane]:
+                continue
+            turn, d1, d2 = int(pt[lane]), int(dice[lane, 0]), int(dice[lane, 1])
+            _, _, cand = O.evaluate_turn_sequences(O.State.from28(pre[lane], turn), turn, d1, d2)
+            want = {tuple(int(v) for v in c) for c in cand}
+            got = {_replay_key(O, pre[lane], turn, d1, d2, k & 0x7FFFFFFF) for k in by_game.get(lane, [])}
+            assert got == want, (ply, lane, len(got), len(want))
+            checked += 1
+    assert checked > 300
+
+
 @pytest.mark.parametrize("n", [1, 63, 65, 777])
 def test_odd_lane_counts(bg, O, weights, n):
     """Lane counts that are not multiples of any wave / workgroup / tile size: every kernel's tail handling and the
