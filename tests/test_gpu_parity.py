@@ -930,6 +930,30 @@ def test_staged_rows_on_edge_boards_and_late_game(bg, O, weights, golden_dir):
             assert got == want, (ply, lane, len(got), len(want))
             checked += 1
     assert checked > 300
+    # arbitrary (unreachable) positions: heavy stacks, both sides on the bar, late bear-off boards, every roll class
+    n3 = 1500
+    st3 = _random_boards(n3, 77)
+    rng = np.random.RandomState(78)
+    turn3 = rng.randint(0, 2, n3).astype(np.int32)
+    dice3 = rng.randint(1, 7, (n3, 2)).astype(np.int32)
+    env = bg.VecGame(n3, arena_rows=1 << 21)
+    env.load_weights(weights)
+    env.set_states(st3, turn3)
+    env.set_dice(dice3)
+    env.step_greedy(roll=False, auto_reset=False)
+    assert env.stats()["error_flags"] == 0
+    info = _np(env.unique_rows_info())
+    by_game = {}
+    for gm, k in info:
+        by_game.setdefault(int(gm), []).append(int(k))
+    for i in range(n3):
+        t, d1, d2 = int(turn3[i]), int(dice3[i, 0]), int(dice3[i, 1])
+        if O.over(O.State.from28(st3[i], t))[0]:
+            continue                                       # a finished board is not stepped
+        _, _, cand = O.evaluate_turn_sequences(O.State.from28(st3[i], t), t, d1, d2)
+        want = {tuple(int(v) for v in c) for c in cand}
+        got = {_replay_key(O, st3[i], t, d1, d2, k & 0x7FFFFFFF) for k in by_game.get(i, [])}
+        assert got == want, (i, len(got), len(want))
 
 
 @pytest.mark.parametrize("n", [1, 63, 65, 777])
