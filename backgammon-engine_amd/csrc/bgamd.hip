@@ -1205,6 +1205,13 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
     env->timing_stride = ((unsigned)enable >> 20) & 0xFFu;                 // (stride << 20): every stride-th launch only
     if (env->timing_stride == 0) env->timing_stride = 1;
     for (unsigned &c : env->timing_seen) c = 0;
+    if (env->timing)                                      // events are created here, not inside somebody's timed region
+        while (env->ev.size() < 2 * 1024) {
+            hipEvent_t x;
+            HIPCHK(hipEventCreate(&x));
+            env->ev.push_back(x);
+            if (env->ev.size() % 2 == 0) env->ev_kind.push_back(0);
+        }
     return BGAMD_OK;
 }
 
