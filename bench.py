@@ -5,7 +5,9 @@ A "step" is one batched env step: every live lane rolls, enumerates its legal tu
 scores every afterstate with the 198->128->1 value net, applies the arg-max/arg-min and
 auto-resets finished games (config 3 of BASELINE.json, weights tdgammonNEW100k -- SURVEY.md
 explains why not bestModel.pth).  value = env steps (live-lane turns) of ALL ranks / wall time
-of the slowest rank, states resident in HBM.
+of the slowest rank, states resident in HBM.  The K timed steps are ONE bgamd_env_run_greedy(K)
+call (the same games as K step_greedy calls; consecutive steps share a launch); the dominant
+kernel is bracketed with HIP events on every 4th of those steps (an event pair costs ~4 us).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
