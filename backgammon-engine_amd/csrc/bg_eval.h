@@ -407,15 +407,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         const long long r0 = tile * 64 + lane;
         nx0 = rows[2 * r0]; nx1 = rows[2 * r0 + 1]; nxi = info[r0];
     }
-    // ... and so are its game's root row and the first 32 hidden units of the root term (issued during the LAST chunk
-    // of the tile before: a tile otherwise starts with two dependent memory round trips and nothing to overlap them)
+    // ... and so is its game's root row (issued during the last pass of the tile before)
     uint4 nr0 = root_rows[2 * (long long)nxi.x], nr1 = root_rows[2 * (long long)nxi.x + 1];
-    f32x4_t nxt[8];
-    {
-        const f32x4_t *ah0 = reinterpret_cast<const f32x4_t *>(root_hidden + (long long)nxi.x * N_HID);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) nxt[j] = ah0[j];
-    }
     while (tile < t_hi) {
         const long long next_tile = grab();
         const long long row = tile * 64 + lane;
@@ -487,39 +480,45 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 32 hidden units at a time: root term (the next chunk's is in flight meanwhile), a += Δ · W1[:, f] over
-        //      the lane's entries (a lane that has run out reads a zero entry = adds 0 x row 0: the FMAs stay
-        //      unconditional and in place), hidden sigmoid, partial dot with W2
+        // ---- 64 hidden units at a time (two halves of 32 pairs): root term, a += Δ · W1[:, f] over the lane's entries (a
+        //      lane that has run out reads a zero entry = adds 0 x row 0: the FMAs stay unconditional and in place),
+        //      hidden sigmoid, partial dot with W2.  (Four passes of 32 units decoded every list entry four times.)
         float sum = 0.0f;
         const f32x4_t *w2v = reinterpret_cast<const f32x4_t *>(sW2);
         const uint32_t sW_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)sW;   // LDS byte address
 #pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            f32x2_t a[16];
+        for (int c = 0; c < 2; ++c) {
+            f32x2_t a[16], a2[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a[2 * j] = nxt[j].lo; a[2 * j + 1] = nxt[j].hi; }
-            {   // next 32 units of this tile, or (last chunk) the next tile's root row and first 32 units
-                const f32x4_t *src = c < 3 ? ah + 8 * (c + 1)
-                                           : reinterpret_cast<const f32x4_t *>(root_hidden + (long long)nxi.x * N_HID);
+            for (int j = 0; j < 8; ++j) { const f32x4_t t = ah[16 * c + j]; a[2 * j] = t.lo; a[2 * j + 1] = t.hi; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nxt[j] = src[j];
-                if (c == 3) { nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1]; }
-            }
+            for (int j = 0; j < 8; ++j) { const f32x4_t t = ah[16 * c + 8 + j]; a2[2 * j] = t.lo; a2[2 * j + 1] = t.hi; }
+            if (c == 1) { nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1]; }   // next tile's root row
             uint32_t ent = lst[0];
             for (uint32_t e = 0; e < maxcnt; ++e) {
                 const uint32_t nent = lst[(e + 1 < DELTA_MAX ? e + 1 : e) * 64];      // next entry: its LDS latency hides here
                 const float d = 0.5f * (float)(int)(int8_t)(ent >> 8);
                 const f32x2_t d2 = {d, d};
-                delta_apply_32(a, d2, sW_lds + (ent & 255u) * (DW_STRIDE * 4) + 128u * (uint32_t)c);
+                const uint32_t addr = sW_lds + (ent & 255u) * (DW_STRIDE * 4) + 256u * (uint32_t)c;
+                delta_apply_32(a, d2, addr);
+                delta_apply_32(a2, d2, addr + 128u);
                 ent = nent;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f32x4_t w = w2v[8 * c + j];
+                const f32x4_t w = w2v[16 * c + j];
                 sum = __builtin_fmaf(w.x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].x)), sum);
                 sum = __builtin_fmaf(w.y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].y)), sum);
                 sum = __builtin_fmaf(w.z, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].x)), sum);
                 sum = __builtin_fmaf(w.w, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].y)), sum);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4_t w = w2v[16 * c + 8 + j];
+                sum = __builtin_fmaf(w.x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j].x)), sum);
+                sum = __builtin_fmaf(w.y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j].y)), sum);
+                sum = __builtin_fmaf(w.z, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j + 1].x)), sum);
+                sum = __builtin_fmaf(w.w, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j + 1].y)), sum);
             }
         }
         __builtin_amdgcn_wave_barrier();
