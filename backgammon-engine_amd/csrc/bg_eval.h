@@ -359,6 +359,16 @@ __device__ __forceinline__ void delta_apply_32(f32x2_t (&a)[16], f32x2_t d2, uin
           "v122", "v123", "v124", "v125", "v126", "v127", "memory");
 }
 
+// sum += w · 1 / (1 + 2^a) for two hidden units (a already carries the -log2 e)
+__device__ __forceinline__ f32x2_t delta_sigmoid_pair(f32x2_t a, f32x2_t w, f32x2_t sum)
+{
+    f32x2_t e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    e = e + (f32x2_t){1.0f, 1.0f};
+    const f32x2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return __builtin_elementwise_fma(w, r, sum);     // (not inline asm: a VALU read right after a transcendental write
+                                                     //  needs a wait state on gfx950, which the compiler inserts)
+}
+
 __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         // ---- 64 hidden units at a time (two halves of 32 pairs): root term, a += Δ · W1[:, f] over the lane's entries (a
         //      lane that has run out reads a zero entry = adds 0 x row 0: the FMAs stay unconditional and in place),
         //      hidden sigmoid, partial dot with W2.  (Four passes of 32 units decoded every list entry four times.)
-        float sum = 0.0f;
+        f32x2_t sum2 = {0.0f, 0.0f};
         const f32x4_t *w2v = reinterpret_cast<const f32x4_t *>(sW2);
         const uint32_t sW_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)sW;   // LDS byte address
 #pragma unroll 1
@@ -504,23 +514,21 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 delta_apply_32(a2, d2, addr + 128u);
                 ent = nent;
             }
+            // hidden sigmoids two units at a time: the "1 +" and the "· W2, +=" are packed fp32 operations
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4_t w = w2v[16 * c + j];
-                sum = __builtin_fmaf(w.x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].x)), sum);
-                sum = __builtin_fmaf(w.y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j].y)), sum);
-                sum = __builtin_fmaf(w.z, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].x)), sum);
-                sum = __builtin_fmaf(w.w, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[2 * j + 1].y)), sum);
+                sum2 = delta_sigmoid_pair(a[2 * j], w.lo, sum2);
+                sum2 = delta_sigmoid_pair(a[2 * j + 1], w.hi, sum2);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4_t w = w2v[16 * c + 8 + j];
-                sum = __builtin_fmaf(w.x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j].x)), sum);
-                sum = __builtin_fmaf(w.y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j].y)), sum);
-                sum = __builtin_fmaf(w.z, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j + 1].x)), sum);
-                sum = __builtin_fmaf(w.w, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a2[2 * j + 1].y)), sum);
+                sum2 = delta_sigmoid_pair(a2[2 * j], w.lo, sum2);
+                sum2 = delta_sigmoid_pair(a2[2 * j + 1], w.hi, sum2);
             }
         }
+        const float sum = sum2.x + sum2.y;
         __builtin_amdgcn_wave_barrier();
         {
             const float v = fast_sigmoid(sum + b2);
