@@ -298,7 +298,8 @@ constexpr int DELTA_MAX = 16;                           // <= 4 moves x (origin,
 constexpr int DELTA_LDS_TOTAL = (DELTA_W_FLOATS + N_HID) * 4 + (DELTA_THREADS / 64) * DELTA_MAX * 64 * 2;   // 16-bit list entries
 
 // W1^T for the incremental kernel, pre-multiplied by -log2(e) (the hidden sigmoid is then rcp(1 + exp2(a))); the rows of
-// the borne-off counters (196, 197: x = n/15) also carry the 1/15, so every list entry is a small multiple of 1/2
+// the borne-off counters (196, 197: x = n/15) also carry the 1/15, so every list entry is a small multiple of 1/2 --
+// and every row carries that 1/2 (exact), so the kernel multiplies by the integer 2Δ
 inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[DW_ROWS][132]*/)
 {
     const float NL2E = -1.44269504088896340736f;
@@ -307,7 +308,7 @@ inline void relayout_w1_delta(const float *w1 /*[128][198]*/, float *wt /*[DW_RO
         for (int n = 0; n < N_HID; ++n) {
             float w = NL2E * w1[n * N_IN + f];
             if (f >= 196) w = w / 15.0f;
-            wt[delta_row(f) * DW_STRIDE + n] = w;
+            wt[delta_row(f) * DW_STRIDE + n] = 0.5f * w;     // list multipliers are 2Δ (integers): the 1/2 lives here, exactly
         }
 }
 
@@ -317,46 +318,54 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // hand (four reads in flight, FMAs issued as each lands) and the packed FMAs pinned IN PLACE.  Left to itself the
 // compiler renamed the loop-carried accumulators every iteration and copied them back, and, short of registers at 4
 // waves per SIMD, serialised the reads with full lgkmcnt(0) waits; the temporaries are the fixed registers v[108:127].
+// (OFF = byte offset of the 32 units inside the 128-float row, an immediate of the reads; the entry's multiplier is the
+// LOW half of d2, broadcast to both halves of the packed FMA by op_sel_hi:[0,1,1])
+#define BG_DA_FMA(ACC, W) "v_pk_fma_f32 " ACC ", %16, " W ", " ACC " op_sel_hi:[0,1,1]\n\t"
+#define BG_DA_BODY(O0, O1, O2, O3, O4, O5, O6, O7)                                                          \
+        "ds_read_b128 v[108:111], %17 offset:" #O0 "\n\t"                                                  \
+        "ds_read_b128 v[112:115], %17 offset:" #O1 "\n\t"                                                  \
+        "ds_read_b128 v[116:119], %17 offset:" #O2 "\n\t"                                                  \
+        "ds_read_b128 v[120:123], %17 offset:" #O3 "\n\t"                                                  \
+        "ds_read_b128 v[124:127], %17 offset:" #O4 "\n\t"                                                  \
+        "s_waitcnt lgkmcnt(4)\n\t" BG_DA_FMA("%0", "v[108:109]") BG_DA_FMA("%1", "v[110:111]")              \
+        "ds_read_b128 v[108:111], %17 offset:" #O5 "\n\t"                                                  \
+        "s_waitcnt lgkmcnt(4)\n\t" BG_DA_FMA("%2", "v[112:113]") BG_DA_FMA("%3", "v[114:115]")              \
+        "ds_read_b128 v[112:115], %17 offset:" #O6 "\n\t"                                                  \
+        "s_waitcnt lgkmcnt(4)\n\t" BG_DA_FMA("%4", "v[116:117]") BG_DA_FMA("%5", "v[118:119]")              \
+        "ds_read_b128 v[116:119], %17 offset:" #O7 "\n\t"                                                  \
+        "s_waitcnt lgkmcnt(4)\n\t" BG_DA_FMA("%6", "v[120:121]") BG_DA_FMA("%7", "v[122:123]")              \
+        "s_waitcnt lgkmcnt(3)\n\t" BG_DA_FMA("%8", "v[124:125]") BG_DA_FMA("%9", "v[126:127]")              \
+        "s_waitcnt lgkmcnt(2)\n\t" BG_DA_FMA("%10", "v[108:109]") BG_DA_FMA("%11", "v[110:111]")            \
+        "s_waitcnt lgkmcnt(1)\n\t" BG_DA_FMA("%12", "v[112:113]") BG_DA_FMA("%13", "v[114:115]")            \
+        "s_waitcnt lgkmcnt(0)\n\t" BG_DA_FMA("%14", "v[116:117]") "v_pk_fma_f32 %15, %16, v[118:119], %15 op_sel_hi:[0,1,1]"
+template <int OFF>
 __device__ __forceinline__ void delta_apply_32(f32x2_t (&a)[16], f32x2_t d2, uint32_t lds_addr)
 {
-    asm volatile(
-        "ds_read_b128 v[108:111], %17\n\t"
-        "ds_read_b128 v[112:115], %17 offset:16\n\t"
-        "ds_read_b128 v[116:119], %17 offset:32\n\t"
-        "ds_read_b128 v[120:123], %17 offset:48\n\t"
-        "ds_read_b128 v[124:127], %17 offset:64\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_pk_fma_f32 %0, %16, v[108:109], %0\n\t"
-        "v_pk_fma_f32 %1, %16, v[110:111], %1\n\t"
-        "ds_read_b128 v[108:111], %17 offset:80\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_pk_fma_f32 %2, %16, v[112:113], %2\n\t"
-        "v_pk_fma_f32 %3, %16, v[114:115], %3\n\t"
-        "ds_read_b128 v[112:115], %17 offset:96\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_pk_fma_f32 %4, %16, v[116:117], %4\n\t"
-        "v_pk_fma_f32 %5, %16, v[118:119], %5\n\t"
-        "ds_read_b128 v[116:119], %17 offset:112\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_pk_fma_f32 %6, %16, v[120:121], %6\n\t"
-        "v_pk_fma_f32 %7, %16, v[122:123], %7\n\t"
-        "s_waitcnt lgkmcnt(3)\n\t"
-        "v_pk_fma_f32 %8, %16, v[124:125], %8\n\t"
-        "v_pk_fma_f32 %9, %16, v[126:127], %9\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_pk_fma_f32 %10, %16, v[108:109], %10\n\t"
-        "v_pk_fma_f32 %11, %16, v[110:111], %11\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_pk_fma_f32 %12, %16, v[112:113], %12\n\t"
-        "v_pk_fma_f32 %13, %16, v[114:115], %13\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_pk_fma_f32 %14, %16, v[116:117], %14\n\t"
-        "v_pk_fma_f32 %15, %16, v[118:119], %15"
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-        : "v"(d2), "v"(lds_addr)
-        : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
-          "v122", "v123", "v124", "v125", "v126", "v127", "memory");
+    static_assert(OFF == 0 || OFF == 128, "two halves of a 64-unit pass");
+#define BG_DA_OPS                                                                                                  \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),  \
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])                 \
+        : "v"(d2), "v"(lds_addr)                                                                                   \
+        : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", \
+          "v122", "v123", "v124", "v125", "v126", "v127", "memory"
+    if (OFF == 0) asm volatile(BG_DA_BODY(0, 16, 32, 48, 64, 80, 96, 112) BG_DA_OPS);
+    else asm volatile(BG_DA_BODY(128, 144, 160, 176, 192, 208, 224, 240) BG_DA_OPS);
+#undef BG_DA_OPS
+}
+#undef BG_DA_BODY
+#undef BG_DA_FMA
+
+// list entry (feature row | multiplier m as int8 << 8) -> LDS address of the row's 64-unit half and m as a float in
+// the low half of d2 (the high half is never read): three VALU operations
+__device__ __forceinline__ void delta_entry(uint32_t ent, uint32_t base, f32x2_t &d2, uint32_t &addr)
+{
+    float d;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+        "v_mul_u32_u24_sdwa %1, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_e32 %1, %4, %1"
+        : "=&v"(d), "=&v"(addr)
+        : "v"(ent), "s"((uint32_t)(DW_STRIDE * 4)), "s"(base));
+    d2.x = d;
 }
 
 // sum += w · 1 / (1 + 2^a) for two hidden units (a already carries the -log2 e)
@@ -507,11 +516,11 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
             uint32_t ent = lst[0];
             for (uint32_t e = 0; e < maxcnt; ++e) {
                 const uint32_t nent = lst[(e + 1 < DELTA_MAX ? e + 1 : e) * 64];      // next entry: its LDS latency hides here
-                const float d = 0.5f * (float)(int)(int8_t)(ent >> 8);
-                const f32x2_t d2 = {d, d};
-                const uint32_t addr = sW_lds + (ent & 255u) * (DW_STRIDE * 4) + 256u * (uint32_t)c;
-                delta_apply_32(a, d2, addr);
-                delta_apply_32(a2, d2, addr + 128u);
+                f32x2_t d2;
+                uint32_t addr;
+                delta_entry(ent, sW_lds + 256u * (uint32_t)c, d2, addr);
+                delta_apply_32<0>(a, d2, addr);
+                delta_apply_32<128>(a2, d2, addr);
                 ent = nent;
             }
             // hidden sigmoids two units at a time: the "1 +" and the "· W2, +=" are packed fp32 operations
