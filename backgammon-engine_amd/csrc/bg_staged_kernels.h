@@ -188,12 +188,20 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
                     const int x = key_origin(nd.key, 0);
                     const uint32_t ma_root = legal_origins(rown, ropp, s.pl, s.dB);
                     uint32_t cand = m0 & ma_root, dup = 0;
-                    while (cand) {
-                        const int y = __ffs(cand) - 1; cand &= cand - 1;
-                        Side a = rown, b = ropp;
-                        apply_move(a, b, s.pl, y, s.dB);
-                        if ((legal_origins(a, b, s.pl, s.dA) >> x) & 1u) dup |= 1u << y;
-                    }
+                    const int zx = x + (s.pl ? -s.dA : s.dA);
+                    if (zx >= 1 && zx <= 24) {
+                        // x lands on the board: its legality after y needs a checker left at x (y == x with a single
+                        // checker there -- the bar included -- is the only way y takes it), nothing else: y moves no
+                        // opposing checker onto x's landing point and leaves no checker on the bar that was not there
+                        dup = cand;
+                        if (((rown.b[0] & ~(rown.b[1] | rown.b[2] | rown.b[3])) >> x) & 1u) dup &= ~(1u << x);
+                    } else
+                        while (cand) {                         // x bears off: y can change that either way, ask
+                            const int y = __ffs(cand) - 1; cand &= cand - 1;
+                            Side a = rown, b = ropp;
+                            apply_move(a, b, s.pl, y, s.dB);
+                            if ((legal_origins(a, b, s.pl, s.dA) >> x) & 1u) dup |= 1u << y;
+                        }
                     // ... and the one checker that takes both dice: "x with d2, on with d1" lands where "x with d1, on
                     // with d2" does.  Same afterstate iff neither stop-over point holds an opposing checker (a hit on
                     // the way is the only thing the order can change) and the first order is legal.
@@ -218,12 +226,15 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
                     // same die, the same landing points.  The twin is the one that is expanded.
                     const int x = key_origin(nd.key, s.len - 1);
                     uint32_t cand = m0 & ((1u << x) - 1u) & legal_origins(prev_own, prev_opp, s.pl, die), dup = 0;
-                    while (cand) {
-                        const int y = __ffs(cand) - 1; cand &= cand - 1;
-                        Side a = prev_own, b = prev_opp;
-                        apply_move(a, b, s.pl, y, die);
-                        if ((legal_origins(a, b, s.pl, die) >> x) & 1u) dup |= 1u << y;
-                    }
+                    const int zx = x + (s.pl ? -die : die);
+                    if (zx >= 1 && zx <= 24) dup = cand;       // x lands on the board and y != x: still legal after y (as above)
+                    else
+                        while (cand) {
+                            const int y = __ffs(cand) - 1; cand &= cand - 1;
+                            Side a = prev_own, b = prev_opp;
+                            apply_move(a, b, s.pl, y, die);
+                            if ((legal_origins(a, b, s.pl, die) >> x) & 1u) dup |= 1u << y;
+                        }
                     m0 &= ~dup;
                     pruned_all = m0 == 0;
                 }
