@@ -160,12 +160,15 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
                                              unsigned long long *out_base, uint32_t *out_total)
 {
     constexpr int NW = NT / 64;
+    (void)np;
     __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
-    __shared__ uint32_t s_par_mask[NT], s_par_game[NT], s_par_key[NT], s_par_off[NT];   // key | die<<27 | turn<<31
+    __shared__ uint32_t s_par_game[NT], s_par_key[NT];     // key | die<<27 | turn<<31
+    __shared__ uint16_t s_child[NT * 15];                  // successor q of the workgroup: parent << 5 | origin (31: the parent itself)
     __shared__ uint32_t s_wave[NW];
     __shared__ unsigned long long s_slot;
     const bool valid = x.valid;
     uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
+    uint32_t succ = 0;                     // their origins
     const Node nd = x.nd;
     if (valid) {
         const uint32_t (&pl_next)[8] = x.pl;
@@ -243,14 +246,20 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
                 else cnt = m0 ? (uint32_t)__popc(m0) : (stuck ? 1u : 0u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s_par_plane[k][threadIdx.x] = s.own.b[k]; s_par_plane[4 + k][threadIdx.x] = s.opp.b[k]; }
-                s_par_mask[threadIdx.x] = m0;
+                succ = m0;
                 s_par_game[threadIdx.x] = nd.game;
                 s_par_key[threadIdx.x] = nd.key | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
         }
     }
     uint32_t total, totB = 0;
     const uint32_t off = block_scan_256<NW, true>(cnt, &total, s_wave);
-    s_par_off[threadIdx.x] = off;
+    {   // the node names its successors: the lane that builds successor q reads (parent, origin) in one access instead
+        // of searching the offsets and stepping through the mask
+        uint16_t *c = s_child + off;
+        const uint32_t tag = threadIdx.x << 5;
+        if (succ == 0 && cnt) *c = (uint16_t)(tag | 31u);
+        while (succ) { const int o = __ffs(succ) - 1; succ &= succ - 1; *c++ = (uint16_t)(tag | (uint32_t)o); }
+    }
     unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
     const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
     const unsigned long long baseA = block_alloc<false>(topA, total, &s_slot);      // the scan just synchronised
@@ -265,22 +274,14 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
     __syncthreads();                                       // parent records and offsets are in place
     if (ok) {
         for (uint32_t q = threadIdx.x; q < total; q += NT) {
-            int lo = 0, hi = np - 1;                       // last parent whose offset is <= q
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_par_off[mid] <= q) lo = mid; else hi = mid - 1;
-            }
-            const int par = lo;
-            uint32_t rank = q - s_par_off[par];
-            uint32_t m = s_par_mask[par];
+            const uint32_t ce = s_child[q];
+            const int par = (int)(ce >> 5), o = (int)(ce & 31u);
             const uint32_t pk = s_par_key[par];
             const int pl = (int)(pk >> 31), die = (int)((pk >> 27) & 7u);
             Side a{{s_par_plane[0][par], s_par_plane[1][par], s_par_plane[2][par], s_par_plane[3][par]}};
             Side b{{s_par_plane[4][par], s_par_plane[5][par], s_par_plane[6][par], s_par_plane[7][par]}};
             uint32_t key = pk & KEY_MASK;
-            if (m) {
-                while (rank--) m &= m - 1;
-                const int o = __ffs(m) - 1;
+            if (o != 31) {
                 apply_move(a, b, pl, o, die);
                 key = key_child(key, o);
             }
