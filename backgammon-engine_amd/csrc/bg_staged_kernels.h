@@ -123,8 +123,8 @@ __global__ __launch_bounds__(LANE_NT) void roots_kernel(EnvView e, StagedView sv
 // rows and cost a third of the step.
 //
 // One LANE PER SUCCESSOR: the node threads only publish their position (11 dwords in LDS) and their successor count;
-// after the scan and ONE allocation per block every successor gets its own lane, which finds its parent by binary
-// search over the offsets, rebuilds the position and writes it to its final place (lane q -> row base + q: coalesced,
+// after the scan and ONE allocation per block every successor gets its own lane, which reads (parent, origin) from the
+// table the node threads filled, rebuilds the position and writes it to its final place (lane q -> row base + q: coalesced,
 // and the rows leave in reference order of the nodes).
 enum { MODE_PLY2 = 1, MODE_PLY3 = 2, MODE_LEAF = 3 };
 // threads per workgroup: every block iteration costs one same-address allocation atomic, so the leaf stage (2 000
