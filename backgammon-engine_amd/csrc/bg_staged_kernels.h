@@ -50,12 +50,18 @@ __device__ __forceinline__ void flag_overflow(const EnvView &e)
 #endif
 constexpr int LANE_NT = BG_LANE_NT;
 
-__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g)
+// pre (optional): the lane's state handed over in registers by the apply of the turn before (boundary_kernel)
+__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr)
 {
     __shared__ uint32_t s_wave[LANE_NT / 64];
     __shared__ unsigned long long s_slot;
     LaneCtx c;
-    lane_begin(e, g, flags, c);
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c.p[k] = pre->p[k];
+        c.meta = pre->meta; c.ply = pre->ply; c.epi = pre->epi;
+        lane_derive(e, g, flags, c);
+    } else lane_begin(e, g, flags, c);
     Side own, opp;
     split_sides(c.p, c.turn, own, opp);
     const bool dbl = c.d1 == c.d2;
@@ -394,7 +400,7 @@ __device__ __forceinline__ bool explore_pick(const EnvView &e, const ExploreView
                                              Side &opp, uint32_t &key, uint32_t &k, uint32_t &C);
 
 __device__ __forceinline__ void apply_body(const EnvView &e, const StagedView &sv, const ExploreView &xv, int flags, float epsilon,
-                                           long long g)
+                                           long long g, LaneCtx *fwd = nullptr)
 {
     LaneCtx c;
     lane_begin(e, g, flags & ~BGAMD_ROLL, c);            // dice were stored by roots_kernel
@@ -438,7 +444,13 @@ __device__ __forceinline__ void apply_body(const EnvView &e, const StagedView &s
         join_sides(own, opp, c.turn, c.p);
     }
     if (c.live) { e.chosen[g] = chosen; e.chosen_seq[g] = cseq; e.chosen_val[g] = cval; e.cand_cnt[g] = ccount; }
-    finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live);
+    uint32_t after[3] = {c.meta, c.ply, c.epi};            // a lane that does not take part keeps its state
+    finish_turn(e, g, c.p, c.turn, c.d1, c.d2, c.ply, c.epi, flags, c.live, after);
+    if (fwd) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fwd->p[k] = c.p[k];
+        fwd->meta = after[0]; fwd->ply = after[1]; fwd->epi = after[2];
+    }
 }
 
 __global__ __launch_bounds__(LANE_NT) void apply_kernel(EnvView e, StagedView sv, ExploreView xv, int flags, float epsilon)
@@ -453,7 +465,8 @@ __global__ __launch_bounds__(LANE_NT) void boundary_kernel(EnvView e, StagedView
                                                            float epsilon)
 {
     const long long g = (long long)blockIdx.x * LANE_NT + threadIdx.x;
-    apply_body(e, sv, xv, flags, epsilon, g);
+    LaneCtx next;                                       // the lane's new state goes on in registers: no read-back
+    apply_body(e, sv, xv, flags, epsilon, g, &next);
     __syncthreads();                                    // finish_turn's statistics scratch is free again
-    roots_body(e, sv_next, flags, g);
+    roots_body(e, sv_next, flags, g, &next);
 }

@@ -75,8 +75,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v)
 }
 
 // Terminal check (game.cpp:388-407), auto-reset / turn flip (train.py:113-120), write-back.
+// fwd (optional, [3]): the lane's meta / ply / episode as they stand after this call (p is updated in place) -- for a
+// caller that goes on with the lane's next turn in the same kernel instead of reading the state back
 __device__ __forceinline__ void finish_turn(const EnvView &e, long long g, uint32_t (&p)[8], int turn, int d1, int d2,
-                                            uint32_t ply, uint32_t epi, int flags, bool live)
+                                            uint32_t ply, uint32_t epi, int flags, bool live, uint32_t *fwd = nullptr)
 {
     uint32_t oflags = 0;
     bool fin = false;
@@ -100,6 +102,7 @@ __device__ __forceinline__ void finish_turn(const EnvView &e, long long g, uint3
         store_planes(e, g, p);
         e.meta[g] = meta_pack(turn, d1, d2, fin);
         e.ply[g] = ply; e.episode[g] = epi; e.flags[g] = oflags;
+        if (fwd) { fwd[0] = meta_pack(turn, d1, d2, fin); fwd[1] = ply; fwd[2] = epi; }
     }
     // counters: wave sums -> one LDS word each -> ONE global atomic per block and counter (same-address global
     // atomics retire at ~10 ns each: a per-wave atomic from 1 024 waves costs more than the kernel itself)
@@ -130,12 +133,11 @@ struct LaneCtx {
     bool live;
 };
 
-__device__ __forceinline__ void lane_begin(const EnvView &e, long long g, int flags, LaneCtx &c)
+// lane_derive: everything lane_begin does after its loads (c.p, c.meta, c.ply, c.epi are in place)
+__device__ __forceinline__ void lane_derive(const EnvView &e, long long g, int flags, LaneCtx &c)
 {
     c.live = g < e.n;
     const long long gg = c.live ? g : 0;
-    load_planes(e, gg, c.p);
-    c.meta = e.meta[gg]; c.ply = e.ply[gg]; c.epi = e.episode[gg];
     if (c.meta & META_FINISHED) c.live = false;
     c.turn = c.meta & 1;
     // head-to-head play (train.py:262-277): only the lanes whose side is to move take part in this call
@@ -145,6 +147,14 @@ __device__ __forceinline__ void lane_begin(const EnvView &e, long long g, int fl
     if (flags & BGAMD_ROLL) { c.d1 = die_from_u32(c.x.x); c.d2 = die_from_u32(c.x.y); }
     else { c.d1 = (c.meta >> 4) & 7; c.d2 = (c.meta >> 8) & 7; }
     if (c.d1 < 1 || c.d1 > 6 || c.d2 < 1 || c.d2 > 6) { c.d1 = 1; c.d2 = 1; }   // Game::last_dice default {1,1}
+}
+
+__device__ __forceinline__ void lane_begin(const EnvView &e, long long g, int flags, LaneCtx &c)
+{
+    const long long gg = g < e.n ? g : 0;
+    load_planes(e, gg, c.p);
+    c.meta = e.meta[gg]; c.ply = e.ply[gg]; c.epi = e.episode[gg];
+    lane_derive(e, g, flags, c);
 }
 
 __device__ __forceinline__ void split_sides(const uint32_t (&p)[8], int turn, Side &own, Side &opp)
