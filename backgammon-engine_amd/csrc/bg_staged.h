@@ -67,6 +67,27 @@ __device__ __forceinline__ unsigned long long block_alloc(unsigned long long *to
     return *s_slot;
 }
 
+// two lists at once, both atomics in flight together: the block waits for one round trip instead of two.  (Inline: the
+// compiler's atomic optimiser reads the first result back through v_readfirstlane before it issues the second.)  Both
+// are issued unconditionally -- for callers whose totals are almost never zero.
+__device__ __forceinline__ void block_alloc2(unsigned long long *topA, uint32_t totA, unsigned long long *topB, uint32_t totB,
+                                             unsigned long long (&s_slot)[2], unsigned long long &baseA, unsigned long long &baseB)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a, b;
+        asm volatile("global_atomic_add_x2 %0, %2, %3, off sc0\n\t"
+                     "global_atomic_add_x2 %1, %4, %5, off sc0\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b)
+                     : "v"(topA), "v"((unsigned long long)totA), "v"(topB), "v"((unsigned long long)totB)
+                     : "memory");
+        s_slot[0] = a; s_slot[1] = b;
+    }
+    __syncthreads();
+    baseA = s_slot[0]; baseB = s_slot[1];
+}
+
 struct StagedView {
     Node *d1, *d2, *f;                    // node lists
     long long cap_d1, cap_d2, cap_f;

@@ -54,7 +54,7 @@ constexpr int LANE_NT = BG_LANE_NT;
 __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr)
 {
     __shared__ uint32_t s_wave[LANE_NT / 64];
-    __shared__ unsigned long long s_slot;
+    __shared__ unsigned long long s_slot[2];
     LaneCtx c;
     if (pre) {
 #pragma unroll
@@ -74,11 +74,14 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
     // non-doubles: first-ply nodes of both die orders are leaf parents (F); a stuck root yields nothing.
     const uint32_t nF = !c.live ? 0u : (dbl ? (ma == 0 ? 1u : 0u) : (uint32_t)(__popc(ma) + __popc(mb)));
     const uint32_t nD = (c.live && dbl) ? (uint32_t)__popc(ma) : 0u;
-    uint32_t totF, totD;
-    uint32_t offF = block_scan_256<LANE_NT / 64>(nF, &totF, s_wave);
-    uint32_t offD = block_scan_256<LANE_NT / 64>(nD, &totD, s_wave);
-    const unsigned long long baseF = block_alloc(&sv.tops[T_F], totF, &s_slot);
-    const unsigned long long baseD = block_alloc(&sv.tops[T_D1], totD, &s_slot);
+    // one scan for both counts (nF <= 30, nD <= 15 per lane: 16 bits each hold a workgroup's totals), both allocations
+    // in flight together
+    uint32_t totFD;
+    const uint32_t offFD = block_scan_256<LANE_NT / 64>(nF | (nD << 16), &totFD, s_wave);
+    const uint32_t totF = totFD & 0xFFFFu, totD = totFD >> 16;
+    uint32_t offF = offFD & 0xFFFFu, offD = offFD >> 16;
+    unsigned long long baseF, baseD;
+    block_alloc2(&sv.tops[T_F], totF, &sv.tops[T_D1], totD, s_slot, baseF, baseD);
     const bool okF = baseF + totF <= (unsigned long long)sv.cap_f, okD = baseD + totD <= (unsigned long long)sv.cap_d1;
     if (!okF || !okD) flag_overflow(e);
     if (c.live) {
