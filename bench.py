@@ -261,10 +261,12 @@ def main():
                        "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d: the flops of the DENSE "
                                "198->128->1 net). frac exceeds 1 because the kernel does not do the dense work: an afterstate "
                                "differs from its game's root in a few thermometer features, so its hidden layer is the root's "
-                               "(one dense f32 MFMA pass per game, root_pass_*) plus w1_columns_per_row columns of W1 in fp32 "
-                               "FMAs; executed_tflops is the arithmetic actually issued. The kernel is bound by LDS gathers of "
-                               "W1 columns (one 512 B column per row and changed feature; lds_gather_TBps against 256 CUs x 128 B/clk x 2.4 GHz; "
-                               "the gather phase alone, 38 % of the kernel by ablation, runs at the LDS peak), not by HBM or the MFMA pipe"})
+                               "(one dense pass per game on the bf16 MFMA with W1 split exactly into three bf16 planes, root_pass_*) plus "
+                               "w1_columns_per_row columns of W1 in fp32 FMAs; executed_tflops is the arithmetic actually issued. "
+                               "The kernel is bound by VALU issue (~75 % of the issue slots by the SQ counters under profiles/: "
+                               "packed FMAs of the gathers, half-rate transcendentals of 128 sigmoids per row, list decoding) together "
+                               "with the LDS gathers of W1 columns (one 512 B column per row and changed feature; lds_gather_TBps "
+                               "against 256 CUs x 128 B/clk x 2.4 GHz), not by HBM or the MFMA pipe"})
         else:
             exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
             ev.update({"kernel": "eval_rows_%s_kernel" % ("f32" if a.precision == "f32_dense" else a.precision),
@@ -277,7 +279,7 @@ def main():
             "eval": ev,
             "leaves": {"kernel": "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
-            "expand": {"kernel": "roots_kernel+expand_kernel<PLY2,PLY3>", "bound": "hbm", "achieved": round(expand_gbs, 2),
+            "expand": {"kernel": "doubles_kernel (plies 2+3 of the doubles turns)", "bound": "hbm", "achieved": round(expand_gbs, 2),
                        "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
                        "avg_ms": round(per["expand"], 4)},
         }
