@@ -7,7 +7,7 @@ auto-resets finished games (config 3 of BASELINE.json, weights tdgammonNEW100k -
 explains why not bestModel.pth).  value = env steps (live-lane turns) of ALL ranks / wall time
 of the slowest rank, states resident in HBM.  The K timed steps are ONE bgamd_env_run_greedy(K)
 call (the same games as K step_greedy calls; consecutive steps share a launch); the dominant
-kernel is bracketed with HIP events on every 4th of those steps (an event pair costs ~4 us).
+kernel is bracketed with HIP events on every 8th of those steps (every 4th in runs shorter than 80 steps; an event pair costs ~4 us).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -155,9 +155,9 @@ def main():
     env.stats()                                   # raises on arena overflow
     env.reset_stats()
     if not a.no_kernel_timing:
-        # the dominant kernel, bracketed live in the timed region on every 4th step (an event pair costs ~4 us of stream
-        # time: bracketing every launch slowed the timed region by 4 %)
-        env.time_kernels(True, groups=("eval",), stride=4)
+        # the dominant kernel, bracketed live in the timed region on every 8th step (every 4th in a short run; an event
+        # pair costs ~4 us of stream time: bracketing every launch slowed the timed region by 4 %, every 4th by 1.5 %)
+        env.time_kernels(True, groups=("eval",), stride=8 if a.steps >= 80 else 4)
         env.kernel_times()
 
     if use_dist:
