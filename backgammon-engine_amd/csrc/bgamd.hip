@@ -560,7 +560,7 @@ struct bgamd_env {
     hipStream_t side = nullptr;            // second stream: the root pass of the value net runs beside the doubles plies
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
     unsigned long long *tops_base = nullptr;   // [2][T_COUNT]; sv.tops points at the set of the last step
-    bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream
+    bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
@@ -661,7 +661,9 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
-    env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr;
+    // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
+    // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
+    env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -175,7 +175,7 @@ int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_t
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
  * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
  * 4 roots+expand (plies 1-3), 5 leaf stage, 6 root term of the incremental value net (on the env's second stream,
- * beside the doubles plies; BGAMD_NO_OVERLAP=1 in the environment keeps it on the caller's stream).  enable: 0 = off, 1 = every group, (mask << 8) | (stride << 20) = only the groups
+ * beside the doubles plies; for envs of 28 672 lanes and more -- smaller ones keep it on the caller's stream, where it is faster; BGAMD_NO_OVERLAP=1 / BGAMD_OVERLAP=1 in the environment force either).  enable: 0 = off, 1 = every group, (mask << 8) | (stride << 20) = only the groups
  * whose bit is set in mask, on every stride-th launch of a group (0 = every launch; an event pair costs ~4 us of
  * stream time, so a timed run samples). */
 int bgamd_env_time_kernels(bgamd_env *env, int enable);
