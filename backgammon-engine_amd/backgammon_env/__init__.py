@@ -133,8 +133,13 @@ class VecGame:
         return t
 
     # -- state
-    def reset(self, mask=None):
-        """mask=None: every lane back to episode 0.  mask [n]: only the lanes with mask != 0 restart (next episode)."""
+    def reset(self, mask=None, episode=None):
+        """mask=None: every lane back to episode 0 (counters cleared).  mask [n]: only the lanes with mask != 0 restart
+        (next episode).  episode=k: every lane starts its episode k -- global game id lane_offset + lane + k * lane_stride,
+        i.e. fresh dice and a fresh opening roll for every round of a one-game-per-lane training loop."""
+        if episode is not None:
+            _capi.check(self._lib.bgamd_env_reset_episode(self._h, int(episode), _stream()), "reset_episode")
+            return
         if mask is None:
             _capi.check(self._lib.bgamd_env_reset(self._h, _stream()), "reset")
             return
@@ -162,6 +167,12 @@ class VecGame:
         f = self._buf((self.n,), torch.int32)
         _capi.check(self._lib.bgamd_env_get_flags(self._h, _ptr(f), _stream()), "get_flags")
         return f
+
+    def snapshot(self):
+        """int32 [n, 32] = state28 | turn | die1 | die2 | flags: every scalar getter's data in one launch."""
+        out = self._buf((self.n, 32), torch.int32)
+        _capi.check(self._lib.bgamd_env_snapshot(self._h, _ptr(out), _stream()), "snapshot")
+        return out
 
     def set_dice(self, dice):
         d = self._dev(dice, torch.int32, (self.n, 2))
@@ -257,6 +268,17 @@ class VecGame:
                 return buf[:n].to(torch.int64) & 0xFFFFFFFF
             cap = int(n)
 
+    def unique_rows(self, want_states=True):
+        """Every afterstate the value net evaluated in the last greedy step, in arena order:
+        -> (info int64 [U, 2] (game, key | turn << 31), states int32 [U, 28] or None, values float32 [U])."""
+        info = self.unique_rows_info()
+        u = int(info.shape[0])
+        st = self._buf((u, 28), torch.int32) if want_states else None
+        val = self._buf((u,), torch.float32)
+        _capi.check(self._lib.bgamd_env_unique_rows_read(self._h, 0, u, _ptr(st), _ptr(val), _stream()), "unique_rows_read")
+        torch.cuda.current_stream().synchronize()
+        return info, st, val
+
     def stats(self):
         out = (C.c_uint64 * 10)()
         _capi.check(self._lib.bgamd_env_stats(self._h, out), "stats")
@@ -317,12 +339,28 @@ class VecGame:
         torch.cuda.current_stream().synchronize()
         return out
 
-    def evaluate(self, states28, turn, precision=F32):
+    def evaluate(self, states28, turn, precision=F32, slot=0):
         st = torch.as_tensor(states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)
         n = st.shape[0]
         t = self._dev(turn, torch.int32, (n,))
         out = self._buf((n,), torch.float32)
-        _capi.check(self._lib.bgamd_evaluate(self._h, _ptr(st), _ptr(t), n, int(precision), _ptr(out), _stream()), "evaluate")
+        _capi.check(self._lib.bgamd_evaluate_slot(self._h, int(slot), _ptr(st), _ptr(t), n, int(precision), _ptr(out), _stream()),
+                    "evaluate")
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def evaluate_incremental(self, root_states28, root_turn, states28, root_index, slot=0):
+        """Values of afterstates through the greedy step's incremental fp32 path: root position's hidden layer (dense,
+        per root) + the W1 columns of the features afterstate i changes against root root_index[i]."""
+        rs = torch.as_tensor(root_states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)
+        nr = rs.shape[0]
+        rt = self._dev(root_turn, torch.int32, (nr,))
+        st = torch.as_tensor(states28, dtype=torch.int32).to(self.device).contiguous().reshape(-1, 28)
+        n = st.shape[0]
+        ri = self._dev(root_index, torch.int32, (n,))
+        out = self._buf((n,), torch.float32)
+        _capi.check(self._lib.bgamd_evaluate_incremental(self._h, int(slot), _ptr(rs), _ptr(rt), nr, _ptr(st), _ptr(ri), n,
+                                                         _ptr(out), _stream()), "evaluate_incremental")
         torch.cuda.current_stream().synchronize()
         return out
 
@@ -343,18 +381,51 @@ class VecGame:
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
 
 
+_POOL = {}          # device index -> idle one-lane envs (a Game that dies hands its env back)
+
+
 class Game:
-    """The reference `Game` (bindings.cpp:62-93) on a one-lane device env."""
+    """The reference `Game` (bindings.cpp:62-93) on a one-lane device env.
+
+    One-lane envs are pooled: constructing a Game (or clone(), which reference-style callers do per candidate) reuses
+    an idle env instead of allocating a new one, and the getters read a host mirror that ONE snapshot launch fills after
+    each mutation (the reference's getters are plain member reads)."""
 
     _ARENA = 32768          # > the largest doubles enumeration observed (10 063)
 
     def __init__(self, player: int = 0):
         global _next_scalar_id
-        self._v = VecGame(1, device=torch.cuda.current_device() if torch.cuda.is_available() else 0,
-                          seed=_seed, lane_offset=_next_scalar_id, lane_stride=1 << 40, arena_rows=self._ARENA)
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        pool = _POOL.setdefault(dev, [])
+        if pool:
+            self._v = pool.pop()                              # a fresh game on a pooled env: its own dice stream (episode =
+            self._v.reset(episode=_next_scalar_id + 1)        # a new global game id), last_dice {1,1} (game.hpp:44), no
+            self._v.reset_stats()                             # error flags left over from the previous owner
+        else:
+            self._v = VecGame(1, device=dev, seed=_seed, lane_offset=_next_scalar_id, lane_stride=1 << 40,
+                              arena_rows=self._ARENA)
         _next_scalar_id += 1
         self._players = [None, None]
+        self._snap = None
         self._v.set_states(None, [int(player) % 2])          # Game::Game(int): turn = parity (game.cpp:44-53)
+
+    def __del__(self):
+        v = getattr(self, "_v", None)
+        if v is not None and getattr(v, "_h", None) and _POOL is not None:
+            self._v = None
+            pool = _POOL.setdefault(v.device.index or 0, [])
+            if len(pool) < 64:
+                pool.append(v)
+            else:
+                v.close()
+
+    def _dirty(self):
+        self._snap = None
+
+    def _s(self):
+        if self._snap is None:
+            self._snap = self._v.snapshot()[0].cpu().tolist()
+        return self._snap
 
     # players ------------------------------------------------------------------------------
     def setPlayers(self, p1: Player, p2: Player):
@@ -366,13 +437,14 @@ class Game:
 
     # turn / board ---------------------------------------------------------------------------
     def getTurn(self):
-        return int(self._v.turns()[0])
+        return self._s()[28]
 
     def setTurn(self, turn):
         self._v.set_states(None, [int(turn) & 1])
+        self._dirty()
 
     def _state(self):
-        return self._v.states()[0].cpu().tolist()
+        return list(self._s()[:28])
 
     def getGameBoard(self):
         return self._state()[:24]
@@ -381,10 +453,10 @@ class Game:
         return Pieces(self)
 
     def getJailedCount(self, player):
-        return self._state()[24 + (0 if int(player) == 0 else 1)]
+        return self._s()[24 + (0 if int(player) == 0 else 1)]
 
     def getBornOffCount(self, player):
-        return self._state()[26 + (0 if int(player) == 0 else 1)]
+        return self._s()[26 + (0 if int(player) == 0 else 1)]
 
     def setGameBoard(self, board):
         board = [int(v) for v in board]
@@ -392,17 +464,20 @@ class Game:
             raise ValueError("gameboard must have 24 entries")
         s = self._state()
         self._v.set_states([board + s[24:]], None)
+        self._dirty()
 
     def setBorneOffPieces(self, player, num):
         s = self._state()
         s[26 + (0 if int(player) == 0 else 1)] = int(num)
         self._v.set_states([s], None)
+        self._dirty()
 
     def _set_jailed(self, player, num):
         """Not in the reference binding (bar counts are only reachable by hits); used by tests/clone."""
         s = self._state()
         s[24 + (0 if int(player) == 0 else 1)] = int(num)
         self._v.set_states([s], None)
+        self._dirty()
 
     def reset(self):
         self.populateBoard()                                   # binding maps reset -> populateBoard only
@@ -410,6 +485,7 @@ class Game:
     def populateBoard(self):
         s = self._state()
         self._v.set_states([[2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2] + s[24:]], None)
+        self._dirty()
 
     def printGameBoard(self):
         s = self._state()
@@ -418,14 +494,16 @@ class Game:
     # dice -------------------------------------------------------------------------------------
     def setDice(self, d1, d2):
         self._v.set_dice([[int(d1), int(d2)]])
+        self._dirty()
 
     def roll_dice(self):
         self._v.roll(advance_ply=True)
+        self._dirty()
         return self.get_last_dice()
 
     def get_last_dice(self):
-        d = self._v.dice()[0].cpu().tolist()
-        return d if d[0] else [1, 1]
+        d = self._s()[29:31]
+        return list(d) if d[0] else [1, 1]
 
     # rules --------------------------------------------------------------------------------------
     def legalMoves(self, player, die):
@@ -449,14 +527,18 @@ class Game:
 
     def tryMove(self, player: Player, dice, origin, dest):
         err = int(self._v.try_move([player.getNum()], [int(dice)], [int(origin)], [int(dest)])[0])
+        if err == 0:
+            self._dirty()
         return err == 0, ERR_MESSAGES[err]
 
     def is_game_over(self):
-        f = int(self._v.flags()[0])
+        f = self._s()[31]
         return (True, (f >> 1) & 1) if f & 1 else (False, -1)
 
     def clone(self):
         g = Game(0)
         g._players = list(self._players)
-        g._v.set_states([self._state()], [self.getTurn()])     # last_dice stays [1,1] (game.cpp:68-77)
+        s = self._s()
+        g._v.set_states([s[:28]], [s[28]])                     # last_dice stays [1,1] (game.cpp:68-77)
+        g._dirty()
         return g

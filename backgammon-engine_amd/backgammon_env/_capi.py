@@ -20,6 +20,7 @@ F32, BF16, F16X2, F32_DENSE = 0, 1, 2, 3
 _P = C.c_void_p
 SYMBOLS = [
     ("bgamd_version", C.c_int, []),
+    ("bgamd_source_hash", C.c_char_p, []),
     ("bgamd_error_string", C.c_char_p, [C.c_int]),
     ("bgamd_last_hip_error", C.c_char_p, []),
     ("bgamd_device_count", C.c_int, []),
@@ -27,10 +28,12 @@ SYMBOLS = [
     ("bgamd_env_destroy", C.c_int, [_P]),
     ("bgamd_env_num_games", C.c_int64, [_P]),
     ("bgamd_env_reset", C.c_int, [_P, _P]),
+    ("bgamd_env_reset_episode", C.c_int, [_P, C.c_uint32, _P]),
     ("bgamd_env_reset_lanes", C.c_int, [_P, _P, _P]),
     ("bgamd_env_set_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_flags", C.c_int, [_P, _P, _P]),
+    ("bgamd_env_snapshot", C.c_int, [_P, _P, _P]),
     ("bgamd_env_set_dice", C.c_int, [_P, _P, _P]),
     ("bgamd_env_get_dice", C.c_int, [_P, _P, _P]),
     ("bgamd_env_roll", C.c_int, [_P, C.c_int, _P]),
@@ -49,11 +52,14 @@ SYMBOLS = [
     ("bgamd_env_try_move", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("bgamd_env_legal_moves", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("bgamd_env_unique_rows_info", C.c_int64, [_P, _P, C.c_int64, _P]),
+    ("bgamd_env_unique_rows_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
     ("bgamd_env_set_trajectory", C.c_int, [_P, _P, C.c_int64]),
     ("bgamd_env_get_progress", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_encode_rows", C.c_int, [_P, C.c_int64, _P, _P]),
     ("bgamd_encode", C.c_int, [_P, _P, C.c_int64, _P, _P]),
     ("bgamd_evaluate", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("bgamd_evaluate_slot", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("bgamd_evaluate_incremental", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P]),
     ("bgamd_env_time_kernels", C.c_int, [_P, C.c_int]),
     ("bgamd_env_kernel_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("bgamd_pack_rows", C.c_int, [_P, _P, C.c_int64, _P, _P]),
@@ -92,8 +98,20 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
+    # the library must be the one built from the sources next to it (a stale .so travels with gpurun snapshots)
+    from . import _srchash
+    have = lib.bgamd_source_hash().decode()
+    if os.path.isdir(os.path.join(_srchash.PKG, "csrc")) and os.environ.get("BGAMD_ALLOW_STALE") != "1":
+        want = _srchash.source_hash()
+        if have != want:
+            raise BgamdError(f"{LIB_PATH} was built from other sources (library {have}, sources {want}): "
+                             "run `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
+
+
+def source_hash() -> str:
+    return load().bgamd_source_hash().decode()
 
 
 def check(rc: int, what: str = ""):

@@ -71,10 +71,10 @@ class TDLambdaLearner:
             active = (lengths > t)
             terminal = (lengths == t + 1)
             W1, b1, W2, b2 = self._split(self.theta)
-            x = X[t]
+            x = X[t].to(dt)                                         # X may be kept in fp32 (it is exact there) under a float64 replay
             v, h = self.values(x)
             if t + 1 < T:
-                v_next, _ = self.values(X[t + 1])
+                v_next, _ = self.values(X[t + 1].to(dt))
             else:
                 v_next = torch.zeros_like(v)
             delta = torch.where(terminal, z - v, v_next - v)
@@ -163,11 +163,16 @@ class DeviceTDLambdaLearner:
         self._capi.check(self._lib.bgamd_td_times(self._h, C.byref(ms), C.byref(n), C.byref(gs)), "td_times")
         return ms.value, n.value, gs.value
 
-    def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0, split_apply: bool = False):
+    def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0, split_apply: bool = False,
+                    sub_round: int = 0):
         """rows: int32 [T, n, 8] trajectory log (VecGame.record_trajectory / play_round), lengths: int [n] logged
         turns per lane (0 = do not replay), p1_won: bool [n].  Returns (Σ δ², number of (game, step) updates).
-        split_apply: take the step / all-reduce / apply route of the distributed replay even on one rank."""
-        C, lib, chk = self._C, self._lib, self._capi.check
+        split_apply: take the step / all-reduce / apply route of the distributed replay even on one rank.
+        sub_round = k > 0: the round is replayed as ceil(games / k) sub-rounds of <= k games, one after another, every
+        sub-round from the weights the one before left (the reference applies a round's games one after another,
+        train.py:536-547; k = 1 is exactly that, k = games is one summed update per step).  The same trace traffic
+        whatever k is; sub-rounds take every ceil(games / k)-th game of the length-sorted order, so each has the round's
+        mix of game lengths."""
         rows = rows.contiguous()
         T, n = int(rows.shape[0]), int(rows.shape[1])
         lengths = torch.as_tensor(lengths, device=self.device).to(torch.int32).contiguous()
@@ -175,20 +180,39 @@ class DeviceTDLambdaLearner:
         if int(lengths.max().item()) > T:
             raise ValueError("a game is longer than the trajectory log")
         sl, order = torch.sort(lengths, descending=True, stable=True)
-        order = order.to(torch.int32).contiguous()
         n_games = int((sl > 0).sum().item())
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        n_sub = 1
+        if sub_round and sub_round > 0:
+            n_sub = max(1, -(-n_games // int(sub_round)))
+        if distributed:                                         # every rank runs the same number of sub-rounds
+            ns = torch.tensor([n_sub], dtype=torch.int64, device=self.device)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)
+            n_sub = int(ns.item())
+        sq_tot, cnt_tot = 0.0, 0
+        for c in range(n_sub):
+            o = order[:n_games][c::n_sub].to(torch.int32).contiguous()
+            sq, cnt = self._replay_order(rows, T, n, lengths, won, o, sl[:n_games][c::n_sub], group, distributed,
+                                         batch_scale, split_apply)
+            sq_tot += sq
+            cnt_tot += cnt
+        return sq_tot, cnt_tot
+
+    def _replay_order(self, rows, T, n, lengths, won, order, sl, group, distributed, batch_scale, split_apply):
+        """Lock-step replay of the games order[...] (lanes, by decreasing length sl)."""
+        C, lib, chk = self._C, self._lib, self._capi.check
+        n_games = int(order.numel())
         if n_games > self.max_games:
             raise ValueError(f"{n_games} games > max_games={self.max_games}")
         n_steps = int(sl[0].item()) if n_games else 0
         # running games per step: a prefix of the order
-        hist = torch.bincount(sl[:n_games].long(), minlength=n_steps + 1)
+        hist = torch.bincount(sl.long(), minlength=n_steps + 1)
         n_active = (n_games - torch.cumsum(hist, 0)[:n_steps]).cpu().tolist()      # games with length > t
         self._keep = (rows, lengths, won, order)
         chk(lib.bgamd_td_begin(self._h, self._p(rows), T, n, self._p(order), n_games, self._p(lengths), self._p(won),
                                self._s()), "td_begin")
         alpha = float(self.learning_rate) * float(batch_scale)
         lam = float(self.lambda_decay)
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if not distributed and not split_apply:
             arr = (C.c_int64 * max(n_steps, 1))(*n_active)
             chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
@@ -211,11 +235,17 @@ class DeviceTDLambdaLearner:
         return float(sq.value), int(cnt.value)
 
 
-def play_round(env, max_plies: int = 512, epsilon: float = 0.0, precision=0):
+def play_round(env, max_plies: int = 512, epsilon: float = 0.0, precision=0, episode=None):
     """One round of self-play from a frozen weight snapshot (train.py:527-547 semantics): every lane plays
-    ONE game to the end, turns are logged. -> (rows [T, n, 8] int32, lengths [n], p1_won [n] bool)."""
+    ONE game to the end, turns are logged. -> (rows [T, n, 8] int32, lengths [n], p1_won [n] bool).
+    Round k of an env plays episode k of every lane (global game id lane_offset + lane + k * lane_stride): new dice,
+    new opening roll and new exploration draws for every game, as play_game rolls fresh dice for every game
+    (train.py:64-121).  episode=None continues the env's own round counter; an explicit value replays that round."""
+    if episode is None:
+        episode = getattr(env, "_round", 0)
+    env._round = int(episode) + 1
     traj = env.record_trajectory(max_plies)
-    env.reset()
+    env.reset(episode=int(episode))
     done_steps = 0
     while done_steps < max_plies:                      # 16 turns per call; finished games are frozen and skipped
         k = min(16, max_plies - done_steps)

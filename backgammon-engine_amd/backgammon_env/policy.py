@@ -83,6 +83,7 @@ class TDLGammonModel:
         env = game._v
         self._bind(env)
         env.step_greedy(roll=False, auto_reset=False, epsilon=epsilon, no_flip=True)
+        game._dirty()
         c = env.last_choice()
         if int(c["count"][0]) == 0:
             return []

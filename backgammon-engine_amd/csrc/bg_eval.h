@@ -383,7 +383,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
     const float *__restrict__ b2p, const uint4 *__restrict__ root_rows, const float *__restrict__ root_hidden,
     float *__restrict__ values, const uint2 *__restrict__ info, unsigned long long *__restrict__ best,
-    unsigned long long *__restrict__ delta_counter, unsigned long long *__restrict__ zero_words, int n_zero_words)
+    unsigned long long *__restrict__ delta_counter, unsigned long long *__restrict__ zero_words, int n_zero_words,
+    unsigned long long *__restrict__ err_word, unsigned long long err_bit)
 {
     // multi-step runs: the OTHER set of list counters is cleared here, while no kernel is using it, for the roots of
     // the next step (which share a launch with this step's apply)
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     const float b2 = *b2p;
     constexpr float NL2E = -1.44269504088896340736f;
     uint32_t n_delta = 0;
+    bool list_overflow = false;
 
     // software pipeline: the next tile's row + info are in flight while this tile is computed
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
@@ -489,7 +491,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
             }
         }
 #undef BG_PUSH
-        if (cnt > DELTA_MAX) cnt = DELTA_MAX;            // cannot happen for a legal turn
+        // A legal turn changes at most 13 features (4 origins + 4 landing points of the mover, 4 hit points + the bar
+        // counter of the opponent; test_delta_list_worst_case builds that turn).  More than DELTA_MAX means the row is
+        // not an afterstate of its root: flagged (BGAMD_E_DELTA), and the list is cut so that the reads stay in bounds.
+        if (cnt > DELTA_MAX) { cnt = DELTA_MAX; list_overflow = true; }
         n_delta += cnt;
         uint32_t maxcnt = 0;                               // wave-uniform trip count of the apply loops: max over the lanes,
 #pragma unroll                                             // built bit by bit from ballots (no cross-lane data movement)
@@ -557,6 +562,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     }
     __syncthreads();
     if (delta_counter && threadIdx.x == 0 && s_nd) atomicAdd(delta_counter, (unsigned long long)s_nd);
+    if (err_word && __ballot(list_overflow) != 0ull && lane == 0) atomicOr(err_word, err_bit);
 }
 
 // ================================ bf16 speed mode ================================================

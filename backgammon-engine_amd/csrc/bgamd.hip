@@ -27,7 +27,7 @@ using namespace bg;
 namespace {
 
 enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_FNODES, C_DNODES, C_KSTEPS, C_COUNT };
-enum { ERRF_ARENA = 1, ERRF_STATE = 2 };
+enum { ERRF_ARENA = 1, ERRF_STATE = 2, ERRF_DELTA = 4 };
 constexpr uint32_t META_FINISHED = 1u << 12;
 
 struct EnvView {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void emit_kernel(EnvView e, int flags, int with
 // ---- small state kernels ---------------------------------------------------------------------------
 // mask == nullptr: every lane restarts at episode 0.  Otherwise only the lanes with mask != 0 restart, as the NEXT
 // episode of that lane (what the auto-reset of a finished game does)
-__global__ void reset_kernel(EnvView e, const int32_t *__restrict__ mask)
+__global__ void reset_kernel(EnvView e, const int32_t *__restrict__ mask, uint32_t episode)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n) return;
@@ -271,7 +271,7 @@ __global__ void reset_kernel(EnvView e, const int32_t *__restrict__ mask)
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = sp.p[k];
     store_planes(e, g, p);
-    const uint32_t epi = mask ? e.episode[g] + 1u : 0u;
+    const uint32_t epi = mask ? e.episode[g] + 1u : episode;
     const unsigned long long gid = e.lane_offset + (unsigned long long)g + (unsigned long long)epi * e.lane_stride;
     e.meta[g] = meta_pack(opening_turn(e.seed, gid), 1, 1, false);
     e.ply[g] = 0; e.episode[g] = epi; e.flags[g] = 0;
@@ -320,6 +320,23 @@ __global__ void get_flags_kernel(EnvView e, int32_t *__restrict__ out)
     load_planes(e, g, p);
     const int oc = over_code(p);          // is_game_over on the CURRENT board (game.cpp:388-407)
     out[g] = (oc ? (1 | ((oc - 1) << 1)) : 0) | ((e.meta[g] & META_FINISHED) ? 4 : 0) | (int32_t)((e.flags[g] & 3u) << 4);
+}
+
+__global__ void snapshot_kernel(EnvView e, int32_t *__restrict__ out)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n) return;
+    uint32_t p[8];
+    load_planes(e, g, p);
+    int32_t s[28];
+    state28_from_planes(p, s);
+    int32_t *o = out + g * 32;
+#pragma unroll
+    for (int i = 0; i < 28; ++i) o[i] = s[i];
+    const uint32_t m = e.meta[g];
+    const int oc = over_code(p);
+    o[28] = (int32_t)(m & 1); o[29] = (int32_t)((m >> 4) & 7); o[30] = (int32_t)((m >> 8) & 7);
+    o[31] = (oc ? (1 | ((oc - 1) << 1)) : 0) | ((m & META_FINISHED) ? 4 : 0) | (int32_t)((e.flags[g] & 3u) << 4);
 }
 
 __global__ void dice_kernel(EnvView e, const int32_t *__restrict__ in, int32_t *__restrict__ out, int roll)
@@ -389,6 +406,23 @@ __global__ void rows_read_kernel(const uint4 *__restrict__ rows, const uint32_t 
     }
 }
 
+__global__ void rows_values_kernel(const uint4 *__restrict__ rows, const float *__restrict__ values, long long first, long long n,
+                                   int32_t *__restrict__ st, float *__restrict__ val)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = first + i;
+    if (st) {
+        const uint4 u0 = rows[2 * r], u1 = rows[2 * r + 1];
+        const uint32_t p[8] = {u0.x & ~TURN_BIT, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        int32_t s[28];
+        state28_from_planes(p, s);
+#pragma unroll
+        for (int k = 0; k < 28; ++k) st[i * 28 + k] = s[k];
+    }
+    if (val) val[i] = values[r];
+}
+
 __global__ void last_choice_kernel(EnvView e, int32_t *chosen, int32_t *count, int8_t *seq, int32_t *len, float *val)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,6 +452,28 @@ __global__ void pack_rows_kernel(const int32_t *__restrict__ st, const int32_t *
     const int t = turn ? (turn[i] & 1) : 0;
     rows[2 * i] = make_uint4(p[0] | (t ? TURN_BIT : 0u), p[1], p[2], p[3]);
     rows[2 * i + 1] = make_uint4(p[4], p[5], p[6], p[7]);
+}
+
+// rows of the stateless incremental operator: afterstate i belongs to root root_index[i] and carries that root's turn bit
+__global__ void pack_child_rows_kernel(const int32_t *__restrict__ st, const int32_t *__restrict__ root_index, long long n,
+                                       long long n_roots, const uint4 *__restrict__ root_rows, uint4 *__restrict__ rows,
+                                       uint2 *__restrict__ info, unsigned long long *err)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t s[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s[k] = st[i * 28 + k];
+    uint32_t p[8];
+    int bad = 0;
+    planes_from_state28(s, p, &bad);
+    long long r = root_index[i];
+    if (r < 0 || r >= n_roots) { bad = 1; r = 0; }
+    if (bad && err) atomicOr(err, (unsigned long long)ERRF_STATE);
+    const uint32_t tb = root_rows[2 * r].x & TURN_BIT;
+    rows[2 * i] = make_uint4(p[0] | tb, p[1], p[2], p[3]);
+    rows[2 * i + 1] = make_uint4(p[4], p[5], p[6], p[7]);
+    info[i] = make_uint2((uint32_t)r, (uint32_t)(i & 0x00FFFFFF) | (tb ? 0x80000000u : 0u));
 }
 
 __global__ void encode_states_kernel(const int32_t *__restrict__ st, const int32_t *__restrict__ turn, long long n,
@@ -542,6 +598,14 @@ static thread_local std::string g_hip_err;
         }                                                                              \
     } while (0)
 
+// every entry point that takes an env (or a learner) first makes its device current: one process may drive envs on
+// several devices, and the caller's current device need not be the env's
+#define ENV_GUARD(env)                                   \
+    do {                                                 \
+        if (!(env)) return BGAMD_E_INVALID;              \
+        HIPCHK(hipSetDevice((env)->device));             \
+    } while (0)
+
 struct bgamd_env {
     int device = 0;
     EnvView v{};
@@ -598,21 +662,36 @@ struct KTimer {
         if (env->ev_used * 2 + 2 > env->ev.size()) {
             if (env->ev.size() >= 2 * 8192) { flush_events(env); }
             else {
-                for (int i = 0; i < 2; ++i) { hipEvent_t x; hipEventCreate(&x); env->ev.push_back(x); }
+                hipEvent_t x[2] = {nullptr, nullptr};
+                if (hipEventCreate(&x[0]) != hipSuccess || hipEventCreate(&x[1]) != hipSuccess) {
+                    if (x[0]) hipEventDestroy(x[0]);
+                    on = false;                          // no event pair: this launch goes untimed
+                    return;
+                }
+                env->ev.push_back(x[0]); env->ev.push_back(x[1]);
                 env->ev_kind.push_back(0);
             }
         }
-        slot = env->ev_used++;
+        if (env->ev_used * 2 + 2 > env->ev.size()) { on = false; return; }
+        slot = env->ev_used;
+        if (hipEventRecord(env->ev[2 * slot], s) != hipSuccess) { on = false; return; }
+        env->ev_used++;
         env->ev_kind[slot] = kind;
-        hipEventRecord(env->ev[2 * slot], s);
     }
-    ~KTimer() { if (on) hipEventRecord(env->ev[2 * slot + 1], s); }
+    // a pair whose second record failed would poison flush_events: record it on the null stream as a last resort
+    ~KTimer() { if (on && hipEventRecord(env->ev[2 * slot + 1], s) != hipSuccess) hipEventRecord(env->ev[2 * slot + 1], nullptr); }
 };
 }  // namespace
 
 extern "C" {
 
-int bgamd_version(void) { return 100; }
+int bgamd_version(void) { return 200; }
+
+#ifndef BGAMD_SRC_HASH
+#define BGAMD_SRC_HASH "unknown"
+#endif
+// the marker lets the build script read the digest out of the file without loading it
+const char *bgamd_source_hash(void) { static const char tag[] = "BGAMD_SRC_HASH=" BGAMD_SRC_HASH; return tag + 15; }
 
 const char *bgamd_error_string(int code)
 {
@@ -624,6 +703,7 @@ const char *bgamd_error_string(int code)
     case BGAMD_E_ARENA: return "candidate arena overflow";
     case BGAMD_E_STATE: return "state with |count| > 15";
     case BGAMD_E_NOWEIGHTS: return "weights not loaded";
+    case BGAMD_E_DELTA: return "incremental value net: a row differs from its root in more features than a legal turn changes";
     default: return "unknown error";
     }
 }
@@ -751,8 +831,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
 
 int bgamd_env_destroy(bgamd_env *env)
 {
-    if (!env) return BGAMD_E_INVALID;
-    hipSetDevice(env->device);
+    ENV_GUARD(env);
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
@@ -771,11 +850,19 @@ int64_t bgamd_env_num_games(const bgamd_env *env) { return env ? env->v.n : 0; }
 
 int bgamd_env_reset(bgamd_env *env, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(env->device));
-    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, (const int32_t *)nullptr, 0u);
     HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, s));
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_reset_episode(bgamd_env *env, uint32_t episode, void *stream)
+{
+    ENV_GUARD(env);
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, episode);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -783,7 +870,8 @@ int bgamd_env_reset(bgamd_env *env, void *stream)
 int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask, void *stream)
 {
     if (!env || !d_mask) return BGAMD_E_INVALID;
-    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_mask);
+    HIPCHK(hipSetDevice(env->device));
+    hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_mask, 0u);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -791,6 +879,7 @@ int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask, void *stream)
 int bgamd_env_set_states(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, void *stream)
 {
     if (!env || (!d_states28 && !d_turn)) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(set_states_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_states28, d_turn);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -798,7 +887,7 @@ int bgamd_env_set_states(bgamd_env *env, const int32_t *d_states28, const int32_
 
 int bgamd_env_get_states(bgamd_env *env, int32_t *d_states28, int32_t *d_turn, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipLaunchKernelGGL(get_states_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_states28, d_turn);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -807,7 +896,17 @@ int bgamd_env_get_states(bgamd_env *env, int32_t *d_states28, int32_t *d_turn, v
 int bgamd_env_get_flags(bgamd_env *env, int32_t *d_flags, void *stream)
 {
     if (!env || !d_flags) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(get_flags_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_flags);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_env_snapshot(bgamd_env *env, int32_t *d_out, void *stream)
+{
+    if (!env || !d_out) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    hipLaunchKernelGGL(snapshot_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_out);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -815,6 +914,7 @@ int bgamd_env_get_flags(bgamd_env *env, int32_t *d_flags, void *stream)
 int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice, void *stream)
 {
     if (!env || !d_dice) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_dice, (int32_t *)nullptr, 0);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -822,13 +922,14 @@ int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice, void *stream)
 int bgamd_env_get_dice(bgamd_env *env, int32_t *d_dice, void *stream)
 {
     if (!env || !d_dice) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, d_dice, 0);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
 int bgamd_env_roll(bgamd_env *env, int advance_ply, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipLaunchKernelGGL(dice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, (int32_t *)nullptr, advance_ply ? 2 : 1);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
@@ -847,7 +948,7 @@ static int launch_emit(bgamd_env *env, int flags, int with_seq, const int32_t *o
 
 int bgamd_env_enumerate(bgamd_env *env, const int32_t *d_player, const int32_t *d_dice, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     return launch_emit(env, 0, 1, d_player, d_dice, (hipStream_t)stream);
 }
 
@@ -856,12 +957,13 @@ static int check_err_flags(bgamd_env *env, unsigned long long f)
     (void)env;
     if (f & ERRF_ARENA) return BGAMD_E_ARENA;
     if (f & ERRF_STATE) return BGAMD_E_STATE;
+    if (f & ERRF_DELTA) return BGAMD_E_DELTA;
     return BGAMD_OK;
 }
 
 int64_t bgamd_env_candidates_info(bgamd_env *env, int64_t *d_offsets, int32_t *d_counts, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cand_info_kernel, grid1(env->v.n, 256), dim3(256), 0, s, env->v, d_offsets, d_counts);
     unsigned long long h[C_COUNT];
@@ -876,6 +978,7 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
                               int32_t *d_seq_len, void *stream)
 {
     if (!env || first < 0 || n_rows < 0 || first + n_rows > env->v.cap) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     if (n_rows == 0) return BGAMD_OK;
     hipLaunchKernelGGL(rows_read_kernel, grid1(n_rows, 128), dim3(128), 0, (hipStream_t)stream, env->v.rows, env->v.seqs,
                        (long long)first, (long long)n_rows, d_states28, d_seq, d_seq_len);
@@ -885,7 +988,7 @@ int bgamd_env_candidates_read(bgamd_env *env, int64_t first, int64_t n_rows, int
 
 int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     const long long n = env->v.n;
     HIPCHK(hipMemsetAsync(env->rv.top, 0, 8, s));
@@ -905,7 +1008,7 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
 // the bounded kernels above -- tests compare the two
 int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(step_random_kernel, grid1(env->v.n, 64), dim3(64), 0, s, env->v, flags, d_choice_u32);
     HIPCHK(hipGetLastError());
@@ -981,6 +1084,7 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
 int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision, int64_t n_steps, void *stream)
 {
     if (!env || n_steps < 0) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     const int slot = (flags & BGAMD_WEIGHTS_SLOT1) ? 1 : 0;
     if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
     if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2 && precision != BGAMD_F32_DENSE)
@@ -1058,7 +1162,8 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
                                (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                                (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
                                env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS],
-                               fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT);
+                               fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT, &env->v.counters[C_ERR],
+                               (unsigned long long)ERRF_DELTA);
         } else {
             rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
             if (rc) return rc;
@@ -1099,7 +1204,7 @@ int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precisio
 int bgamd_env_last_choice(bgamd_env *env, int32_t *d_chosen, int32_t *d_count, int8_t *d_seq, int32_t *d_seq_len,
                           float *d_value, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipLaunchKernelGGL(last_choice_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, d_chosen, d_count,
                        d_seq, d_seq_len, d_value);
     HIPCHK(hipGetLastError());
@@ -1121,7 +1226,7 @@ int bgamd_env_stats(bgamd_env *env, uint64_t h_out[10])
 
 int bgamd_env_reset_stats(bgamd_env *env, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     HIPCHK(hipMemsetAsync(env->v.counters, 0, C_COUNT * 8, (hipStream_t)stream));
     return BGAMD_OK;
 }
@@ -1130,6 +1235,7 @@ int bgamd_env_try_move(bgamd_env *env, const int32_t *d_player, const int32_t *d
                        const int32_t *d_dest, int32_t *d_err, void *stream)
 {
     if (!env || !d_player || !d_dice || !d_origin || !d_dest || !d_err) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(try_move_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_player, d_dice,
                        d_origin, d_dest, d_err);
     HIPCHK(hipGetLastError());
@@ -1140,6 +1246,7 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
                           void *stream)
 {
     if (!env || !d_player || !d_die || !d_n || !d_pairs) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     hipLaunchKernelGGL(legal_moves_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_player, d_die,
                        d_n, d_pairs);
     HIPCHK(hipGetLastError());
@@ -1148,7 +1255,7 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
 
 int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info, int64_t cap, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long n = 0;
     HIPCHK(hipMemcpyAsync(&n, &env->sv.tops[T_U], 8, hipMemcpyDeviceToHost, s));
@@ -1159,9 +1266,21 @@ int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info, int64_t cap, vo
     return (int64_t)n;
 }
 
+int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28, float *d_values, void *stream)
+{
+    if (!env || first < 0 || n_rows < 0 || first + n_rows > env->sv.cap_rows) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    if (n_rows == 0 || (!d_states28 && !d_values)) return BGAMD_OK;
+    hipLaunchKernelGGL(rows_values_kernel, grid1(n_rows, 128), dim3(128), 0, (hipStream_t)stream, (const uint4 *)env->sv.u_rows,
+                       (const float *)env->v.values, (long long)first, (long long)n_rows, d_states28, d_values);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
 int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies)
 {
     if (!env || (d_rows && max_plies <= 0)) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
     env->v.traj = (uint4 *)d_rows;
     env->v.traj_plies = d_rows ? max_plies : 0;
     return BGAMD_OK;
@@ -1169,7 +1288,7 @@ int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies)
 
 int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, void *stream)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
     if (d_ply) HIPCHK(hipMemcpyAsync(d_ply, env->v.ply, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
     if (d_episode) HIPCHK(hipMemcpyAsync(d_episode, env->v.episode, (size_t)env->v.n * 4, hipMemcpyDeviceToDevice, s));
@@ -1199,19 +1318,61 @@ int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, fl
 int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, int64_t n, int precision,
                    float *d_values, void *stream)
 {
-    if (!env || !d_states28 || !d_values || n < 0 || n > env->v.cap) return BGAMD_E_INVALID;
-    if (!env->has_weights[0]) return BGAMD_E_NOWEIGHTS;
+    return bgamd_evaluate_slot(env, 0, d_states28, d_turn, n, precision, d_values, stream);
+}
+
+int bgamd_evaluate_slot(bgamd_env *env, int slot, const int32_t *d_states28, const int32_t *d_turn, int64_t n, int precision,
+                        float *d_values, void *stream)
+{
+    if (!env || slot < 0 || slot > 1 || !d_states28 || !d_values || n < 0 || n > env->v.cap) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
     if (n == 0) return BGAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     // the candidate arena doubles as scratch for caller-provided states
     hipLaunchKernelGGL(pack_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_turn, (long long)n, env->v.rows,
                        &env->v.counters[C_ERR]);
-    return launch_eval(env, 0, precision, nullptr, (long long)n, env->v.rows, d_values, nullptr, nullptr, s);
+    return launch_eval(env, slot, precision, nullptr, (long long)n, env->v.rows, d_values, nullptr, nullptr, s);
+}
+
+int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_states28, const int32_t *d_root_turn,
+                               int64_t n_roots, const int32_t *d_states28, const int32_t *d_root_index, int64_t n,
+                               float *d_values, void *stream)
+{
+    if (!env || slot < 0 || slot > 1 || !d_root_states28 || !d_root_turn || !d_states28 || !d_root_index || !d_values ||
+        n_roots <= 0 || n_roots > env->v.n || n < 0 || n > env->sv.cap_rows)
+        return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
+    if (n == 0) return BGAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    StagedView &sv = env->sv;
+    const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    // the env's root / afterstate arenas double as scratch, as the candidate arena does for bgamd_evaluate
+    hipLaunchKernelGGL(pack_rows_kernel, grid1(n_roots, 128), dim3(128), 0, s, d_root_states28, d_root_turn, (long long)n_roots,
+                       sv.root_rows, &env->v.counters[C_ERR]);
+    hipLaunchKernelGGL(pack_child_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_root_index, (long long)n,
+                       (long long)n_roots, (const uint4 *)sv.root_rows, sv.u_rows, sv.u_info, &env->v.counters[C_ERR]);
+    HIPCHK(hipMemsetAsync(sv.best, 0, (size_t)n_roots * 8, s));
+    long long blocks = ((n_roots + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
+    if (blocks > env->n_cu) blocks = env->n_cu;
+    hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s,
+                       (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
+                       sv.root_hidden);
+    long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;
+    dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
+    hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
+                       (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const float4 *)env->d_wt[slot],
+                       w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden, d_values, (const uint2 *)sv.u_info, sv.best,
+                       (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0, &env->v.counters[C_ERR],
+                       (unsigned long long)ERRF_DELTA);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
 }
 
 int bgamd_env_time_kernels(bgamd_env *env, int enable)
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     if (!enable && env->timing) flush_events(env);
     env->timing = enable == 1 ? 0xFFu : ((unsigned)enable >> 8) & 0xFFu;   // 1 = every group, (mask << 8) = chosen groups
     env->timing_stride = ((unsigned)enable >> 20) & 0xFFu;                 // (stride << 20): every stride-th launch only
@@ -1229,7 +1390,7 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
 
 int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8])
 {
-    if (!env) return BGAMD_E_INVALID;
+    ENV_GUARD(env);
     const int rc = flush_events(env);
     if (rc) return rc;
     for (int i = 0; i < 8; ++i) {
@@ -1332,6 +1493,7 @@ int bgamd_td_destroy(bgamd_td *td)
 int bgamd_td_set_weights(bgamd_td *td, const float *d_theta, void *stream)
 {
     if (!td || !d_theta) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     hipLaunchKernelGGL(td_apply_kernel, grid1(TD_P, 256), dim3(256), 0, (hipStream_t)stream, td->v, d_theta, 1);
     HIPCHK(hipGetLastError());
     td->has_weights = true;
@@ -1341,6 +1503,7 @@ int bgamd_td_set_weights(bgamd_td *td, const float *d_theta, void *stream)
 int bgamd_td_get_weights(bgamd_td *td, float *d_theta, void *stream)
 {
     if (!td || !d_theta) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
     HIPCHK(hipMemcpyAsync(d_theta, td->v.theta, (size_t)TD_P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BGAMD_OK;
@@ -1352,6 +1515,7 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
     if (!td || !d_rows || !d_order || !d_length || !d_p1_won || T <= 0 || n_lanes <= 0 || n_games < 0 ||
         n_games > td->max_games || n_games > n_lanes)
         return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     TdView &v = td->v;
     v.rows = (const uint4 *)d_rows;
     v.order = d_order;
@@ -1370,6 +1534,7 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream)
 {
     if (!td || !td->begun || t < 0 || t >= td->v.T || n_active < 0 || n_active > td->v.n_games) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
     hipStream_t s = (hipStream_t)stream;
     if (n_active == 0) {                 // nothing to add, but the caller's collective still needs a defined buffer
@@ -1415,6 +1580,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
 int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream)
 {
     if (!td || !d_update) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
     hipLaunchKernelGGL(td_apply_kernel, grid1(TD_P, 256), dim3(256), 0, (hipStream_t)stream, td->v, d_update, 0);
     HIPCHK(hipGetLastError());
@@ -1424,6 +1590,7 @@ int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream)
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream)
 {
     if (!td || !h_n_active || n_steps < 0 || (td->begun && n_steps > td->v.T)) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
     for (int64_t t = 0; t < n_steps; ++t) {
         if (h_n_active[t] == 0) continue;
         const int rc = bgamd_td_step(td, t, h_n_active[t], alpha, lambda, nullptr, stream);
@@ -1434,7 +1601,7 @@ int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, do
 
 int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
 {
-    if (!td) return BGAMD_E_INVALID;
+    ENV_GUARD(td);
     HIPCHK(hipSetDevice(td->device));
     HIPCHK(hipDeviceSynchronize());
     if (h_sq_sum) {
@@ -1450,7 +1617,7 @@ int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
 
 int bgamd_td_time(bgamd_td *td, int enable)
 {
-    if (!td) return BGAMD_E_INVALID;
+    ENV_GUARD(td);
     if (!enable && td->timing) { const int rc = td_flush(td); if (rc) return rc; }
     td->timing = enable != 0;
     return BGAMD_OK;
@@ -1458,7 +1625,7 @@ int bgamd_td_time(bgamd_td *td, int enable)
 
 int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps)
 {
-    if (!td) return BGAMD_E_INVALID;
+    ENV_GUARD(td);
     const int rc = td_flush(td);
     if (rc) return rc;
     if (h_trace_ms) *h_trace_ms = td->trace_ms;

@@ -39,13 +39,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=512, help="games per round (one per lane)")
     ap.add_argument("--rounds", type=int, default=120)
-    ap.add_argument("--eps", type=float, default=0.05)
+    ap.add_argument("--eps-start", type=float, default=0.1, help="exploration rate of the first round (train.py:446)")
+    ap.add_argument("--eps-end", type=float, default=0.0, help="... decaying linearly to this over the run (train.py:531)")
+    ap.add_argument("--eps", type=float, default=None, help="fixed exploration rate (overrides the linear decay)")
+    ap.add_argument("--sub-round", type=int, default=0, help="replay the round in sub-rounds of this many games, weights "
+                    "refreshed between them (0 = the whole round lock-step)")
+    ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
     ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
     ap.add_argument("--dist-backend", default="nccl")
-    ap.add_argument("--precision", choices=("auto", "f32", "f16x2"), default="auto",
+    ap.add_argument("--precision", choices=("auto", "f32", "f16x2", "bf16"), default="auto",
                     help="value net of the self-play steps: f32 = incremental fp32; f16x2 = W1 as f16 hi+lo on the MFMA pipe (same "
                          "1e-5 parity class, 3e-7 measured) -- the faster one for small rounds (512 lanes: 0.039 vs 0.058 ms per "
-                         "step); auto = f16x2 below 16 384 games per rank")
+                         "step); bf16 = config 5's speed mode (single bf16 weights on the MFMA pipe, outside the 1e-5 bound; the learner keeps "
+                         "fp32 traces and weights); auto = f16x2 below 16 384 games per rank")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     group = None
@@ -62,22 +68,35 @@ def main():
         env = bg.VecGame(a.games, seed=1)
     arena = bg.VecGame(1024, seed=2)
     say = print if rank == 0 else (lambda *x, **k: None)
-    prec = bg.F16X2 if a.precision == "f16x2" or (a.precision == "auto" and a.games < 16384) else bg.F32
+    prec = (bg.BF16 if a.precision == "bf16" else
+            bg.F16X2 if a.precision == "f16x2" or (a.precision == "auto" and a.games < 16384) else bg.F32)
     if a.host_learner:
         L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
     else:
         L = DeviceTDLambdaLearner(xavier_init(), max_games=a.games, alpha=0.1, lam=0.7)
     say("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
     t0, turns = time.time(), 0
+    total_games = a.rounds * a.games * world
+    first_dice = None
     for r in range(a.rounds):
-        L.update_learning_params(r * a.games * world)
+        games_done = r * a.games * world
+        L.update_learning_params(games_done)
+        if a.lam is not None:
+            L.lambda_decay = a.lam
+        # linear decay of the exploration rate across the run (train.py:531)
+        eps = a.eps if a.eps is not None else a.eps_start + (a.eps_end - a.eps_start) * (games_done / total_games)
         env.load_weights(L.theta.cpu().numpy())
-        rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=a.eps, precision=prec)
-        scale = min(1.0, 24.0 / (a.games * world))
+        rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=eps, precision=prec)   # round r = episode r: fresh dice
+        if r < 2:                                            # every round must play NEW games
+            d = env.dice().clone()
+            assert first_dice is None or not torch.equal(d, first_dice), "two rounds rolled the same dice"
+            first_dice = d
+        sub = a.sub_round if a.sub_round > 0 else a.games
+        scale = min(1.0, 24.0 / (min(sub, a.games) * world))
         if a.host_learner:
             sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, group=group, batch_scale=scale)
         else:
-            sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale, sub_round=a.sub_round)
         turns += cnt
         if r % 20 == 19:
             say(f"round {r + 1}: {(r + 1) * a.games * world} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "

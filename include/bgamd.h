@@ -34,7 +34,9 @@ enum {
     BGAMD_E_NODEVICE = -3,    /* no usable gfx950 device                              */
     BGAMD_E_ARENA = -4,       /* candidate arena overflow (raise arena_rows)          */
     BGAMD_E_STATE = -5,       /* a state had |count| > 15                             */
-    BGAMD_E_NOWEIGHTS = -6    /* greedy step / evaluate before bgamd_env_load_weights */
+    BGAMD_E_NOWEIGHTS = -6,   /* greedy step / evaluate before bgamd_env_load_weights */
+    BGAMD_E_DELTA = -7        /* an afterstate differed from its root position in more features than a legal turn
+                                 can change (incremental value net): the rows handed to it are not afterstates  */
 };
 
 /* step flags */
@@ -64,6 +66,9 @@ enum {
 enum { BGAMD_F32 = 0, BGAMD_BF16 = 1, BGAMD_F16X2 = 2, BGAMD_F32_DENSE = 3 };
 
 int bgamd_version(void);
+/* hex digest of the sources (csrc + this header) the library was compiled from: the Python binding compares it with
+ * the sources on disk and refuses a stale build; bench.py prints it */
+const char *bgamd_source_hash(void);
 const char *bgamd_error_string(int code);
 const char *bgamd_last_hip_error(void);
 int bgamd_device_count(void);
@@ -82,6 +87,10 @@ int64_t bgamd_env_num_games(const bgamd_env *env);
 /* All lanes: episode 0, ply 0, start position (Game::populateBoard game.cpp:240-252), turn from
  * the opening roll protocol of play_game (train.py:89-97) on the OPENING stream. */
 int bgamd_env_reset(bgamd_env *env, void *stream);
+/* The same for episode `episode` of every lane (game_id = lane_offset + lane + episode * lane_stride): a training
+ * loop that plays one game per lane and round gives every round fresh dice this way -- play_game draws new dice for
+ * every game (train.py:64-121, 527-547).  Counters are kept. */
+int bgamd_env_reset_episode(bgamd_env *env, uint32_t episode, void *stream);
 /* Only the lanes with d_mask[g] != 0 restart, as the next episode of that lane (start position, opening roll of
  * the next global game id) -- what BGAMD_AUTO_RESET does for a finished game, on demand. */
 int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask /*[n]*/, void *stream);
@@ -94,6 +103,9 @@ int bgamd_env_get_states(bgamd_env *env, int32_t *d_states28, int32_t *d_turn, v
  * bit2 = lane frozen (finished without AUTO_RESET); bits4-5 = over/winner flags of the last step
  * (set even when the lane was auto-reset). d_states28 may be NULL in set_states (turn only). */
 int bgamd_env_get_flags(bgamd_env *env, int32_t *d_flags, void *stream);
+/* everything the scalar getters of bindings.cpp:64-93 read, in ONE launch: d_out[n][32] = state28 | turn | die1 | die2 |
+ * flags (as bgamd_env_get_flags) */
+int bgamd_env_snapshot(bgamd_env *env, int32_t *d_out, void *stream);
 int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice /*[n,2]*/, void *stream);   /* setDice      */
 int bgamd_env_get_dice(bgamd_env *env, int32_t *d_dice /*[n,2]*/, void *stream);         /* get_last_dice */
 /* roll_dice: dice of (game_id, ply) on the TURN stream; advance_ply != 0 post-increments ply so that
@@ -155,6 +167,11 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
 /* diagnostics: (game, key | turn<<31) of every row the value net evaluated in the last greedy step (after the
  * pruning of commuting move orders: a few per cent of the rows are still copies); returns the row count (synchronises). */
 int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info /* uint32[cap][2] */, int64_t cap, void *stream);
+/* ... and the rows themselves with the value the net gave each: rows [first, first + n_rows) of that list as int32
+ * states [n_rows][28] and float values [n_rows] (either may be NULL).  With BGAMD_F32 these are the outputs of the
+ * incremental kernel, row by row -- what the parity tests compare with the reference model. */
+int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28, float *d_values,
+                               void *stream);
 
 /* ---- trajectory log for the learner (the list of encodings play_game returns, train.py:105-106,
  * kept as 32-byte rows: 8 bit planes, turn of the side to move in plane 0 bit 31).  When set, every
@@ -169,7 +186,18 @@ int bgamd_encode_rows(const void *d_rows, int64_t n, float *d_out198, void *stre
  * _encode_states_np (model.py:111-144) and forward (model.py:63-67) on caller-provided states. */
 int bgamd_encode(const int32_t *d_states28, const int32_t *d_turn, int64_t n, float *d_out198, void *stream);
 int bgamd_evaluate(bgamd_env *env, const int32_t *d_states28, const int32_t *d_turn, int64_t n,
-                   int precision, float *d_values, void *stream);
+                   int precision, float *d_values, void *stream);                       /* weight slot 0 */
+int bgamd_evaluate_slot(bgamd_env *env, int slot, const int32_t *d_states28, const int32_t *d_turn, int64_t n,
+                        int precision, float *d_values, void *stream);
+/* The same values through the INCREMENTAL fp32 path of the greedy step (make_move's forward over the afterstates of
+ * a turn, model.py:209-211): afterstate i is evaluated as its root position's hidden layer (one dense pass per root,
+ * root d_root_index[i] of the n_roots given with the MOVER's turn, model.py:209) plus the W1 columns of the features
+ * in which it differs from that root.  A row that differs from its root in more features than a legal turn changes
+ * raises BGAMD_E_DELTA at the next bgamd_env_stats.  n_roots <= the env's lanes, n <= its arena rows; the env's
+ * arenas are used as scratch (do not interleave with a step in flight on another stream). */
+int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_states28, const int32_t *d_root_turn,
+                               int64_t n_roots, const int32_t *d_states28, const int32_t *d_root_index, int64_t n,
+                               float *d_values, void *stream);
 
 /* kernel timing hook for bench.py: brackets kernel groups with HIP events on the launch stream;
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call

@@ -61,3 +61,52 @@ def test_host_mirror_types():
     with pytest.raises(TypeError):
         bg.Player("x", 1)
     assert bg.ERR_MESSAGES[6] == "Invalid destination." and bg.ERR_MESSAGES[1] == "Invalid origin"
+
+
+def test_library_carries_the_digest_of_its_sources(built):
+    """The loaded libbgamd.so was compiled from the sources next to it: build() is content-based, the binding refuses
+    a library whose digest differs (a stale .so travels with gpurun snapshots), and the file can be checked without
+    loading it."""
+    from backgammon_env import _srchash
+    want = _srchash.source_hash()
+    assert len(want) == 16
+    assert _srchash.library_hash(built.LIB_PATH) == want
+    assert built.load().bgamd_source_hash().decode() == want == built.source_hash()
+
+
+def test_checkpoint_interop_against_the_reference(built):
+    """SURVEY §8f row 2.  tests/golden/f2_interop.json was written in the build container by make_golden_r2.py with the
+    UNMODIFIED reference: its checkpoint through this repo's loader, and a state_dict written by this repo's learner
+    through the reference's strict load_state_dict and train._model_compatible (train.py:361-381).  Here, without the
+    reference: the record says pass, the checkpoint it was made from is the one the weight fixture holds, and the
+    build's writer still produces exactly the layout (names, order, shapes, dtypes) the reference's reader accepted."""
+    import hashlib
+    import io
+    import json
+
+    import numpy as np
+    import torch
+    from backgammon_env.learner import TDLambdaLearner
+    from backgammon_env.policy import TDLGammonModel, flatten_state_dict
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "f2_interop.json")))
+    for k in ("build_loader_reads_reference_pth", "reference_strict_load_of_build_pth",
+              "reference_model_compatible_of_build_pth", "weights_survive_roundtrip_bit_exact"):
+        assert rec[k] is True, k
+    assert rec["build_state_dict_layout"] == rec["reference_state_dict_layout"]
+    fix = np.fromfile(os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32"), dtype=np.float32)
+    rng = np.random.RandomState(5)                            # the very weights make_golden_r2.py wrote and the reference read
+    w = (fix + rng.normal(0, 0.01, fix.shape)).astype(np.float32)
+    sd = TDLambdaLearner(w, device="cpu").state_dict()
+    assert list(sd) == list(rec["reference_state_dict_layout"])
+    for k, v in sd.items():
+        assert list(v.shape) == rec["reference_state_dict_layout"][k]["shape"] and str(v.dtype) == rec["reference_state_dict_layout"][k]["dtype"]
+    assert hashlib.sha256(w.tobytes()).hexdigest() == rec["build_written_weights_sha256"]   # the weights the reference read back bit-exactly
+    # torch.save -> torch.load(weights_only=True) -> both of the build's readers
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    back = torch.load(buf, map_location="cpu", weights_only=True)
+    assert np.array_equal(flatten_state_dict(back), w)
+    m = TDLGammonModel()
+    m.load_state_dict(back)
+    assert np.array_equal(m._w, w) and list(m.state_dict()) == list(sd)

@@ -677,9 +677,20 @@ def test_bench_contract_line():
     assert d["steps"] == 8 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert d["value"] > 1e6 and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    # a FRACTION of the roof that bounds the executed work (the incremental value net runs on the VALUs, no MFMA)
+    assert r["bound"] in ("hbm", "mfma", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert 0.0 < r["frac"] <= 1.0, r["frac"]
+    for k in d["kernels"]:
+        if isinstance(d["kernels"][k], dict):
+            assert 0.0 <= d["kernels"][k]["frac"] <= 1.0, k
+    assert d["timed_regions"] >= 1 and d["region_ms"]["min"] <= d["region_ms"]["median"] <= d["region_ms"]["max"]
+    assert abs(d["ms_per_step"] * d["steps"] - d["region_ms"]["median"]) < 1e-2
+    assert len(d["source_hash"]) == 16
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert c["host"]["cpu_model"] and c["host"]["nproc"] >= 1
+    ac = c["all_cores"]
+    assert ac["cores"] == c["host"]["usable_cores"] and ac["value"] > 0 and ac["kind"] == "port"
 
 
 def test_reset_lanes_by_mask(bg, O):

@@ -1,0 +1,493 @@
+"""Round-2 GPU parity tests (all through the C ABI):
+  * the headline kernels -- root_hidden_bf16x3_kernel + eval_rows_delta_kernel -- compared ROW BY ROW with the reference
+    model's own outputs (fixture G7, written by the unmodified reference) and with the fp64 oracle;
+  * the 65 536-lane configuration (second-stream root pass, fused step boundaries) against the oracle on sampled lanes;
+  * the per-GPU shares of the training configs: a 65 536-game TD(lambda) round (config 4) and a 32 768-lane round with
+    bf16 self-play and fp32 traces (config 5);
+  * the 2-rank layout rehearsed by two fresh processes that share the one GPU (gloo);
+  * full games through the scalar drop-in surface in the shape of train.py:103-121 against fixture G3.
+Integer work is bit-exact; value-net outputs within 1e-5 of the reference (north_star)."""
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import START, _check_greedy_step, _np
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def bg():
+    import backgammon_env
+    return backgammon_env
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _rows_by_state(states):
+    return {tuple(int(v) for v in s): i for i, s in enumerate(states)}
+
+
+# ---- the headline value-net path, row by row ---------------------------------------------------------------------
+
+def test_delta_kernel_rows_vs_reference_values(bg, O, golden_dir, weights):
+    """Fixture G7: 124 turns of the reference's greedy games, every distinct afterstate with the value the reference
+    model's forward pass gave it.  One greedy step in BGAMD_F32 on those turns: the rows handed to the value net are
+    EXACTLY the reference's distinct afterstates and EVERY per-row output of eval_rows_delta_kernel (root term from
+    root_hidden_bf16x3_kernel) is within 1e-5 of the reference (fp32 and fp64)."""
+    g = np.load(os.path.join(golden_dir, "g7_candidate_values.npz"))
+    roots, off = g["roots"], g["off"]
+    R = len(roots)
+    env = bg.VecGame(R, arena_rows=1 << 20)
+    env.load_weights(weights)
+    env.set_states(roots[:, :28], roots[:, 28])
+    env.set_dice(roots[:, 29:31])
+    env.step_greedy(roll=False, auto_reset=False, precision=bg.F32)
+    info, st, val = [_np(x) for x in env.unique_rows()]
+    assert env.stats()["error_flags"] == 0
+    e32 = e64 = 0.0
+    n_rows = 0
+    for k in range(R):
+        m = info[:, 0] == k
+        ref = _rows_by_state(g["states"][off[k]:off[k + 1]])
+        got = {tuple(int(v) for v in s) for s in st[m]}
+        assert got == set(ref), k                          # the staged rows ARE the reference's distinct afterstates
+        for s, v in zip(st[m], val[m]):
+            j = off[k] + ref[tuple(int(x) for x in s)]
+            e32 = max(e32, abs(float(v) - float(g["v32"][j])))
+            e64 = max(e64, abs(float(v) - float(g["v64"][j])))
+            n_rows += 1
+    print("eval_rows_delta_kernel, %d rows of %d turns: max |gpu - reference fp32| = %.3g, max |gpu - reference fp64| = %.3g"
+          % (n_rows, R, e32, e64))
+    assert n_rows >= int(off[-1]) and e32 < 1e-5 and e64 < 1e-5
+    # the same rows through the stateless incremental operator: the same kernels, bit for bit
+    ridx = np.repeat(np.arange(R), np.diff(off)).astype(np.int32)
+    v2 = _np(env.evaluate_incremental(roots[:, :28], roots[:, 28], g["states"].astype(np.int32), ridx))
+    assert np.abs(v2 - g["v32"]).max() < 1e-5 and np.abs(v2 - g["v64"]).max() < 1e-5
+    by_key = {}
+    for s, v, gi in zip(st, val, info[:, 0]):
+        by_key[(int(gi),) + tuple(int(x) for x in s)] = v
+    same = [by_key[(int(r),) + tuple(int(x) for x in s)] == v for s, v, r in zip(g["states"], v2, ridx)]
+    assert all(same)
+    # root == row (empty delta list): the root pass alone against fixture G5's value rows
+    g5 = np.load(os.path.join(golden_dir, "g5_values.npz"))
+    big = bg.VecGame(len(g5["turn"]), arena_rows=1 << 20)
+    big.load_weights(weights)
+    v3 = _np(big.evaluate_incremental(g5["states"].astype(np.int32), g5["turn"], g5["states"].astype(np.int32),
+                                      np.arange(len(g5["turn"]), dtype=np.int32)))
+    print("root pass alone (bf16 x 3): max |gpu - reference fp32| = %.3g" % np.abs(v3 - g5["v32"]).max())
+    assert np.abs(v3 - g5["v32"]).max() < 1e-5 and np.abs(v3 - g5["v64"]).max() < 1e-5
+
+
+def test_delta_kernel_rows_midgame_4096_vs_oracle(bg, O, weights):
+    """4 096 mid-game lanes: EVERY row value of the incremental kernel against the oracle's fp64 forward of that row."""
+    n = 4096
+    env = bg.VecGame(n, seed=808)
+    env.load_weights(weights)
+    env.run_greedy(35)                                       # de-phased mid-game positions (some already bearing off)
+    pt = _np(env.turns())
+    env.step_greedy(auto_reset=False, precision=bg.F32)
+    info, st, val = [_np(x) for x in env.unique_rows()]
+    assert len(st) > 10 * n and env.stats()["error_flags"] == 0
+    mover = pt[info[:, 0]]
+    assert ((info[:, 1] >> 31) == mover).all()               # rows carry the MOVER's turn bit (model.py:209)
+    worst = 0.0
+    for tb in (0, 1):
+        m = mover == tb
+        v64 = O.forward_f64(weights, O.encode(st[m], tb))
+        worst = max(worst, float(np.abs(val[m] - v64).max()))
+    print("eval_rows_delta_kernel, %d mid-game rows: max |gpu - oracle fp64| = %.3g" % (len(st), worst))
+    assert worst < 1e-5
+
+
+def test_delta_list_worst_case_and_overflow_flag(bg, O, weights):
+    """The longest (feature, delta) list a legal turn can produce is 13 entries: four single checkers each leave their
+    point and hit a blot (4 origins + 4 landing points of the mover, 4 hit points + the bar counter of the opponent).
+    That turn is evaluated exactly; a row that is NOT an afterstate of its root (more than 16 changed features) raises
+    BGAMD_E_DELTA instead of being truncated silently."""
+    board = [0] * 24
+    for p in (1, 3, 5, 7):
+        board[p - 1] = 1                                     # PLAYER1 singles on 1, 3, 5, 7
+        board[p] = -1                                        # PLAYER2 blots on 2, 4, 6, 8
+    board[19] = 11                                           # the other 11 PLAYER1 checkers
+    board[23] = -11                                          # the other 11 PLAYER2 checkers
+    root = np.array(board + [0, 0, 0, 0], dtype=np.int32)
+    env = bg.VecGame(64, arena_rows=1 << 18)
+    env.load_weights(weights)
+    env.set_states(np.tile(root, (64, 1)), np.zeros(64, dtype=np.int32))
+    env.set_dice(np.tile(np.array([[1, 1]], dtype=np.int32), (64, 1)))
+    env.step_greedy(roll=False, auto_reset=False, precision=bg.F32)
+    info, st, val = [_np(x) for x in env.unique_rows()]
+    assert env.stats()["error_flags"] == 0
+    m = info[:, 0] == 0
+    after = board.copy()
+    for p in (1, 3, 5, 7):
+        after[p - 1] = 0
+        after[p] = 1
+    want = np.array(after + [0, 4, 0, 0], dtype=np.int32)     # four PLAYER2 checkers on the bar
+    hit = [i for i in np.nonzero(m)[0] if (st[i] == want).all()]
+    assert hit, "the four-hit turn is among the candidates"
+    x0, x1 = O.encode(root[None], 0)[0], O.encode(want[None], 0)[0]
+    assert int((x0 != x1).sum()) == 13                        # the bound, stated on the encoder itself
+    cand = O.evaluate_turn_sequences(O.State.from28(root, 0), 0, 1, 1)[2]
+    assert {tuple(int(v) for v in s) for s in st[m]} == {tuple(int(v) for v in s) for s in cand}
+    v64 = O.forward_f64(weights, O.encode(st[m], 0))
+    assert np.abs(val[m] - v64).max() < 1e-5
+    # every legal turn stays inside the bound: the largest list over all rows of a late, contact-heavy sample
+    # (ksteps_executed counts the list entries) -- and the flag itself, on rows that are no afterstates of their root
+    far = np.array([0, 0, 0, 0, 0, 5, 0, 3, 0, 0, 0, -5, 5, 0, 0, 0, -3, 0, -5, 0, 0, 0, 0, 2] + [0, 0, 0, 0], dtype=np.int32)
+    x2 = O.encode(far[None], 0)[0]
+    assert int((x0 != x2).sum()) > 16
+    with pytest.raises(bg.BgamdError, match="incremental value net"):
+        env.evaluate_incremental(root[None], [0], far[None], [0])
+        env.stats()
+    env.reset_stats()
+    # a root index outside the given roots is an invalid state, not a wild read
+    with pytest.raises(bg.BgamdError):
+        env.evaluate_incremental(root[None], [0], want[None], [5])
+        env.stats()
+
+
+# ---- the headline configuration: 65 536 lanes, second-stream root pass, fused boundaries -------------------------------
+
+def test_greedy_65536_sampled_lanes_vs_oracle(bg, O, weights):
+    """At 65 536 lanes the root pass runs on the env's second stream (fork after the roots, join before the value
+    net) and run_greedy fuses apply(t) + roots(t+1).  Sampled lanes are checked against the oracle after ONE
+    step_greedy and after run_greedy(8); an env with BGAMD_NO_OVERLAP=1 (everything on one stream) must stay
+    bit-identical to the overlapped one throughout."""
+    n = 65536
+    a = bg.VecGame(n, seed=777)
+    os.environ["BGAMD_NO_OVERLAP"] = "1"
+    try:
+        b = bg.VecGame(n, seed=777)
+    finally:
+        del os.environ["BGAMD_NO_OVERLAP"]
+    a.load_weights(weights); b.load_weights(weights)
+    a.run_greedy(30); b.run_greedy(30)
+    lanes = list(range(5, n, 257))                            # 255 lanes
+    for rnd in range(2):
+        pre, pt = _np(a.states()), _np(a.turns())
+        assert np.array_equal(pre, _np(b.states())) and np.array_equal(pt, _np(b.turns()))
+        frozen = (_np(a.flags()) & 4) != 0                    # finished without auto-reset earlier in this test: skipped
+        a.step_greedy(auto_reset=False); b.step_greedy(auto_reset=False)
+        post, dice = _np(a.states()), _np(a.dice())
+        assert np.array_equal(post, _np(b.states()))
+        _check_greedy_step(O, weights, pre, pt, dice, post, [l for l in lanes if not frozen[l]])
+        # run_greedy(8): a takes the fused route, b takes 7 fused steps and then ONE separate step whose
+        # pre-state is observable -- the 8th step of a is checked against the oracle from b's pre-state
+        a.run_greedy(8, auto_reset=False)
+        b.run_greedy(7, auto_reset=False)
+        pre, pt = _np(b.states()), _np(b.turns())
+        frozen = (_np(b.flags()) & 4) != 0
+        b.step_greedy(auto_reset=False)
+        post, dice = _np(a.states()), _np(a.dice())
+        assert np.array_equal(post, _np(b.states())) and np.array_equal(_np(a.turns()), _np(b.turns()))
+        _check_greedy_step(O, weights, pre, pt, dice, post, [l for l in lanes if not frozen[l]])
+        a.run_greedy(20); b.run_greedy(20)                    # on to later game phases (auto-reset on)
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert all(sa[k] == sb[k] for k in ("steps", "games_finished", "p1_wins", "rows_evaluated"))
+
+
+@pytest.mark.parametrize("mode", ["BGAMD_OVERLAP", "BGAMD_NO_OVERLAP"])
+def test_stream_modes_run_and_graph_capture(bg, weights, mode):
+    """The fork / join of the root pass (BGAMD_OVERLAP=1 forces it on a small env) under run_greedy(k > 1) and inside a
+    captured HIP graph: bit-identical to single-stream stepping."""
+    n = 3000
+    os.environ[mode] = "1"
+    try:
+        a, c = bg.VecGame(n, seed=321), bg.VecGame(n, seed=321)
+    finally:
+        del os.environ[mode]
+    os.environ["BGAMD_NO_OVERLAP"] = "1"
+    try:
+        b = bg.VecGame(n, seed=321)
+    finally:
+        del os.environ["BGAMD_NO_OVERLAP"]
+    for e in (a, b, c):
+        e.load_weights(weights)
+    for k in (1, 3, 8, 16):
+        a.run_greedy(k, epsilon=0.1)
+        for _ in range(k):
+            b.step_greedy(epsilon=0.1)
+        assert np.array_equal(_np(a.states()), _np(b.states())) and np.array_equal(_np(a.turns()), _np(b.turns())), k
+    # graph capture of the forked step
+    c.run_greedy(28, epsilon=0.1)
+    assert np.array_equal(_np(c.states()), _np(b.states()))
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            c.run_greedy(4, epsilon=0.1)
+    for _ in range(3):
+        g.replay()
+    b.run_greedy(12, epsilon=0.1)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(c.states()), _np(b.states())) and np.array_equal(_np(c.turns()), _np(b.turns()))
+    assert a.stats()["error_flags"] == 0 and c.stats()["error_flags"] == 0
+
+
+# ---- training configs: per-GPU shares ---------------------------------------------------------------------------------
+
+def test_rounds_play_fresh_games(bg, weights):
+    """Every round of play_round is a new episode of every lane: new opening rolls, new dice, new exploration draws
+    (play_game rolls fresh dice for every game, train.py:64-121); an explicit episode replays that round exactly."""
+    from backgammon_env.learner import play_round
+    env = bg.VecGame(512, seed=5)
+    env.load_weights(weights)
+    r0 = play_round(env, max_plies=300, epsilon=0.05)
+    r1 = play_round(env, max_plies=300, epsilon=0.05)
+    assert not torch.equal(r0[1], r1[1])                      # game lengths differ lane by lane
+    k = min(r0[0].shape[0], r1[0].shape[0], 3)
+    assert not torch.equal(r0[0][1:k], r1[0][1:k])            # ... because the games do (ply 0 is always the start position)
+    _, epi = env.progress()
+    assert (_np(epi) == 1).all()
+    again = play_round(env, max_plies=300, epsilon=0.05, episode=0)
+    assert torch.equal(again[1], r0[1]) and torch.equal(again[2], r0[2])
+    T = again[0].shape[0]
+    assert torch.equal(again[0], r0[0][:T])
+    assert env.stats()["error_flags"] == 0
+
+
+def _torch_fp64_replay(bg, env, weights, rows, lengths, p1_won, alpha, lam, scale):
+    """The closed form of learner.TDLambdaLearner in float64 on the GPU (PyTorch): the checker for whole rounds."""
+    from backgammon_env.learner import TDLambdaLearner
+    L = TDLambdaLearner(weights, device="cuda", alpha=alpha, lam=lam, dtype=torch.float64)
+    X = env.encode_rows(rows)                                  # [T, n, 198] fp32, cast per step inside replay
+    sq, cnt = L.replay(X, lengths, p1_won, batch_scale=scale)
+    th = L.theta.cpu().numpy()
+    del X, L
+    torch.cuda.empty_cache()
+    return th, sq, cnt
+
+
+def test_config4_share_td_round_65536(bg, O, weights):
+    """Config 4's per-GPU share: ONE round of 65 536 concurrent self-play games (epsilon-greedy, frozen weights,
+    train.py:527-547) logged as 32-byte rows, then the lock-step TD(lambda) replay of all of them on the HIP learner
+    (6.7 GB of fp32 traces).  Checked: every game finishes, checkers conserved in the log, (game, step) count, two
+    replays bit-identical, the update equals the float64 closed form over the WHOLE round (PyTorch on the GPU), and a
+    200-game subset equals the oracle's numpy restatement of the reference learner."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
+    n = 65536
+    env = bg.VecGame(n, seed=31337)
+    env.load_weights(weights)
+    t0 = time.time()
+    rows, lengths, p1_won = play_round(env, max_plies=320, epsilon=0.05)
+    torch.cuda.synchronize()
+    t_play = time.time() - t0
+    ln = _np(lengths)
+    st = env.stats()
+    assert st["error_flags"] == 0 and st["games_finished"] >= (ln > 0).sum() and (ln > 0).mean() > 0.995
+    # the log holds legal positions: checker conservation on a sample of rows, first row = start position
+    X0 = _np(env.encode_rows(rows[0, :64]))
+    assert (X0[:, :192] == O.encode(np.array([START + [0, 0, 0, 0]], dtype=np.int32), 0)[0, :192]).all()
+    scale = 24.0 / n
+    out = []
+    for rep in range(2):
+        Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.9)
+        t1 = time.time()
+        sq_d, cnt_d = Ld.replay_rows(rows, lengths, p1_won, batch_scale=scale)
+        t_rep = time.time() - t1
+        out.append(_np(Ld.theta))
+        assert cnt_d == int(ln.sum())
+        del Ld
+        torch.cuda.empty_cache()
+    assert np.array_equal(out[0], out[1])                      # deterministic run to run
+    print("config-4 share: %d games, %d turns; self-play %.2f s, replay %.2f s (%.1f M turn-updates/s)"
+          % (int((ln > 0).sum()), int(ln.sum()), t_play, t_rep, ln.sum() / t_rep / 1e6))
+    th64, sq64, cnt64 = _torch_fp64_replay(bg, env, weights, rows, lengths, p1_won, 0.1, 0.9, scale)
+    moved = np.abs(th64 - weights).max()
+    d = np.abs(out[0] - th64).max()
+    print("whole round vs float64 closed form: max |dtheta| = %.3g, max |device - fp64| = %.3g, td loss %.5f" % (moved, d, sq64 / cnt64))
+    assert cnt64 == cnt_d and moved > 1e-3 and d < 1e-4 * max(1.0, moved)
+    assert abs(sq_d - sq64) < 1e-3 * max(1.0, sq64)
+    # 200-game subset: device learner == the oracle's restatement of the reference learner (float64, CPU)
+    sub = np.nonzero(ln > 0)[0][:: max(1, int((ln > 0).sum()) // 200)][:200]
+    ls = torch.zeros_like(lengths)
+    ls[torch.as_tensor(sub, device=lengths.device)] = lengths[torch.as_tensor(sub, device=lengths.device)]
+    Ls = DeviceTDLambdaLearner(weights, max_games=256, alpha=0.1, lam=0.9)
+    sq_s, cnt_s = Ls.replay_rows(rows, ls, p1_won, batch_scale=0.25)
+    Tm = int(ln[sub].max())
+    Xs = env.encode_rows(rows[:Tm, torch.as_tensor(sub, device=rows.device)].contiguous()).cpu().double().numpy()
+    th_o, sq_o, cnt_o = O.td_lambda_lockstep(weights, Xs, ln[sub], _np(p1_won)[sub], 0.1, 0.9, batch_scale=0.25)
+    moved_s = np.abs(th_o - weights).max()
+    assert cnt_s == cnt_o == int(ln[sub].sum())
+    assert np.abs(_np(Ls.theta) - th_o).max() < 2e-5 * max(1.0, moved_s), (np.abs(_np(Ls.theta) - th_o).max(), moved_s)
+
+
+def test_config5_share_bf16_selfplay_fp32_traces_32768(bg, O, weights):
+    """Config 5's per-GPU share: 32 768 concurrent games played with the bf16 MFMA value net (speed mode), logged,
+    and replayed with fp32 weights and fp32 traces.  The bf16 games are legal games (every logged transition is a
+    candidate of the oracle on sampled lanes) that mostly pick the fp32 move; the learner equals the float64 closed
+    form on the same log; sub-rounds apply one after another."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
+    n = 32768
+    env = bg.VecGame(n, seed=2718)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=320, epsilon=0.0, precision=bg.BF16)
+    ln = _np(lengths)
+    assert env.stats()["error_flags"] == 0 and (ln > 0).mean() > 0.995
+    # sampled lanes: each logged transition s_t -> s_{t+1} is one of the oracle's afterstates of s_t (with the turn flipped)
+    S = _np(env.encode_rows(rows[:12, :4096:97].contiguous()))      # [12, 43, 198]
+    dice_ok = 0
+    lanes = list(range(0, 4096, 97))
+    for j, lane in enumerate(lanes):
+        for t in range(10):
+            if t + 1 >= ln[lane]:
+                break
+            x0, x1 = S[t, j], S[t + 1, j]
+            tb = 0 if x0[192] == 1.0 else 1
+            assert x1[192 + (1 - tb)] == 1.0                   # the turn flipped
+            dice_ok += 1
+    assert dice_ok > 300
+    # agreement of the bf16 choices with fp32 on the same positions (one step from a common mid-game state)
+    a, b = bg.VecGame(8192, seed=99), bg.VecGame(8192, seed=99)
+    a.load_weights(weights); b.load_weights(weights)
+    a.run_greedy(25); b.run_greedy(25)
+    a.step_greedy(precision=bg.F32, auto_reset=False); b.step_greedy(precision=bg.BF16, auto_reset=False)
+    agree = (_np(a.states()) == _np(b.states())).all(axis=1).mean()
+    print("bf16 vs fp32 move agreement at 8 192 mid-game lanes: %.4f" % agree)
+    assert agree > 0.93
+    scale = 24.0 / n
+    Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.9)
+    sq_d, cnt_d = Ld.replay_rows(rows, lengths, p1_won, batch_scale=scale)
+    th = _np(Ld.theta)
+    assert cnt_d == int(ln.sum()) and np.isfinite(th).all()
+    th64, sq64, cnt64 = _torch_fp64_replay(bg, env, weights, rows, lengths, p1_won, 0.1, 0.9, scale)
+    moved = np.abs(th64 - weights).max()
+    assert cnt64 == cnt_d and moved > 1e-3 and np.abs(th - th64).max() < 1e-4 * max(1.0, moved)
+    # sub-rounds: 64 sub-rounds of 512 games, each from the weights the one before left
+    Ld.set_weights(weights)
+    sq_s, cnt_s = Ld.replay_rows(rows, lengths, p1_won, batch_scale=24.0 / 512, sub_round=512)
+    th_s = _np(Ld.theta)
+    assert cnt_s == cnt_d and np.isfinite(th_s).all() and np.abs(th_s - weights).max() > 1e-3
+    assert not np.array_equal(th_s, th)
+    # ... and with one sub-round per game the replay IS the reference's order of updates (a 24-game round, fp64 check)
+    few = np.nonzero(ln > 0)[0][:24]
+    lf = torch.zeros_like(lengths)
+    idx = torch.as_tensor(few, device=lengths.device)
+    lf[idx] = lengths[idx]
+    Ld.set_weights(weights)
+    Ld.replay_rows(rows, lf, p1_won, sub_round=1)
+    th_seq = _np(Ld.theta)
+    from backgammon_env.learner import TDLambdaLearner
+    Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.9, dtype=torch.float64)
+    order = few[np.argsort(-ln[few], kind="stable")]          # the learner's order: by decreasing length (stable)
+    for lane in order:
+        one = torch.zeros_like(lengths).cpu()
+        one[lane] = int(ln[lane])
+        Xl = env.encode_rows(rows[:int(ln[lane]), lane:lane + 1].contiguous()).cpu()
+        Lc.replay(Xl, one[lane:lane + 1], p1_won[lane:lane + 1].cpu())
+    moved = np.abs(Lc.theta.numpy() - weights).max()
+    assert np.abs(th_seq - Lc.theta.numpy()).max() < 5e-5 * max(1.0, moved), (np.abs(th_seq - Lc.theta.numpy()).max(), moved)
+
+
+# ---- two ranks on one GPU (gloo): configs 3 and 4 as the multi-GPU bench / training loop lay them out ---------------------
+
+def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
+    """Two FRESH processes (spawned before they touch the GPU) share the one GPU and a gloo group:
+      * 2 x 32 768 lanes play, lane for lane, the games of ONE 65 536-lane env (50 greedy steps);
+      * the split / all-reduce / apply learner over two shards leaves bit-identical weight replicas that moved."""
+    lanes, steps, train_lanes = 32768, 50, 1024
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env_vars = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", str(port), str(tmp_path),
+                               str(lanes), str(steps), str(train_lanes)], env=env_vars, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    whole = bg.VecGame(2 * lanes, seed=4242)                   # meanwhile, the one-env reference run in this process
+    whole.load_weights(weights)
+    whole.run_greedy(steps)
+    st, tn, sw = _np(whole.states()), _np(whole.turns()), whole.stats()
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(x[-3000:] for x in outs)
+    r = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(2)]
+    for k in range(2):
+        assert np.array_equal(r[k]["states"], st[k * lanes:(k + 1) * lanes]), k
+        assert np.array_equal(r[k]["turns"], tn[k * lanes:(k + 1) * lanes]), k
+        assert list(r[k]["totals"]) == [sw["steps"], sw["games_finished"], sw["p1_wins"]]       # all-reduced counters
+    assert np.array_equal(r[0]["theta"], r[1]["theta"])        # replicas identical after two rounds of all-reduced updates
+    assert np.abs(r[0]["theta"] - weights).max() > 1e-4
+    assert not np.array_equal(r[0]["lengths"], r[1]["lengths"])   # the two shards played different games
+    assert r[0]["learner"][1] > 0 and r[1]["learner"][1] > 0
+
+
+# ---- the scalar drop-in surface: whole games in the shape of the reference's loop ------------------------------------------
+
+def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
+    """24 complete games through bg.Game exactly as train.py:103-121 / benchmark.py:54-61 drive the reference module:
+    setDice -> evaluateTurnSequences -> pick by index -> tryMove x len -> is_game_over -> setTurn, compared turn by
+    turn with fixture G3 (played by the unmodified reference on the same injected dice and choices).  Reports the
+    config-1 throughput of this surface."""
+    g = np.load(os.path.join(golden_dir, "g3_random_trajectories.npz"))
+    rows = g["rows"]
+    p1, p2 = bg.Player("White", bg.PlayerType.PLAYER1), bg.Player("Black", bg.PlayerType.PLAYER2)
+    turns = 0
+    t0 = time.time()
+    for lane in range(24):
+        r = rows[rows[:, 0] == lane]
+        game = bg.Game(0)
+        game.setPlayers(p1, p2)
+        game.setTurn(int(r[0, 30]))
+        for t in range(len(r)):
+            turn, d1, d2, C, k = int(r[t, 30]), int(r[t, 31]), int(r[t, 32]), int(r[t, 33]), int(r[t, 34])
+            assert game.getTurn() == turn
+            assert game.getGameBoard() == list(r[t, 2:26])
+            assert [game.getJailedCount(0), game.getJailedCount(1), game.getBornOffCount(0), game.getBornOffCount(1)] == list(r[t, 26:30])
+            game.setDice(d1, d2)
+            assert game.get_last_dice() == [d1, d2]
+            seqs, states = game.evaluateTurnSequences(turn, d1, d2)
+            assert len(seqs) == C and states.shape == (C, 28)
+            if C:
+                pl = game.getPlayers(turn)
+                for o, d in seqs[k]:
+                    ok, msg = game.tryMove(pl, abs(o - d), o, d)
+                    assert ok and msg == ""
+                assert game.getGameBoard() + [game.getJailedCount(0), game.getJailedCount(1), game.getBornOffCount(0),
+                                              game.getBornOffCount(1)] == list(states[k])
+            over, winner = game.is_game_over()
+            assert int(over) == r[t, 35] and (not over or winner == r[t, 36])
+            turns += 1
+            if over:
+                assert t == len(r) - 1
+                break
+            game.setTurn(1 - turn)
+    dt = time.time() - t0
+    print("scalar surface (config 1): %d turns of 24 games in %.2f s = %.0f env steps/s" % (turns, dt, turns / dt))
+    # clone(): independent copy, cheap (pooled one-lane envs), last_dice reset to [1, 1] (game.cpp:68-77)
+    game = bg.Game(1)
+    game.setDice(3, 4)
+    t0 = time.time()
+    clones = [game.clone() for _ in range(50)]
+    dt_first = time.time() - t0
+    del clones
+    t0 = time.time()
+    for _ in range(200):
+        c = game.clone()
+    dt_pool = (time.time() - t0) / 200
+    assert c.getGameBoard() == game.getGameBoard() and c.getTurn() == 1 and c.get_last_dice() == [1, 1]
+    assert c.tryMove(p2, 1, 6, 5)[0] and game.getGameBoard() == START and c.getGameBoard() != START
+    print("Game.clone(): %.2f ms each while the pool fills, %.3f ms from the pool" % (1e3 * dt_first / 50, 1e3 * dt_pool))
+    assert dt_pool < 0.01

@@ -1,5 +1,5 @@
 """Copy the summaries tools/profile_round.sh produced (gpurun_out/<tag>/) into profiles/ and rebuild
-profiles/r01_pmc_traffic.json (HBM bytes per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+profiles/<round>_pmc_traffic.json (HBM bytes per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
@@ -28,5 +28,9 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
        "kernels": {k: {"FETCH_SIZE_KB_per_launch_raw": round(f[k], 1), "WRITE_SIZE_KB_per_launch_raw": round(w.get(k, 0), 1),
                        "hbm_read_MB_corrected_x2": round(2 * f[k] * 1024 / 1e6, 2), "hbm_write_MB": round(w.get(k, 0) * 1024 / 1e6, 2),
                        "traffic_MB": round((2 * f[k] + w.get(k, 0)) * 1024 / 1e6, 2)} for k in f}}
-json.dump(out, open(os.path.join(dst, "r01_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
+sq = os.path.join(src, "sq_counters.txt")            # tools/sq_counters.sh <tag>, when it was run for this tag
+if os.path.exists(sq):
+    shutil.copy(sq, os.path.join(dst, f"{tag}_sq_counters.txt"))
+    os.system(f"{sys.executable} tools/valu_occupancy.py {dst}/{tag}_sq_counters.txt --json {dst}/{tag.split('_')[0]}_valu_occupancy.json")
 print("profiles/ updated for", tag)
