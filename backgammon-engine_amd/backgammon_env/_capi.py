@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbgamd.so")
+# BGAMD_LIB: a differently-flagged build of the SAME sources (tools/ab_build.sh, A/B measurements); the digest check applies to it too
+LIB_PATH = os.environ.get("BGAMD_LIB") or os.path.join(os.path.dirname(_HERE), "libbgamd.so")
 
 OK = 0
 ROLL, AUTO_RESET, NO_FLIP, WANT_INDEX, ONLY_P1, ONLY_P2, WEIGHTS_SLOT1 = 1, 2, 4, 8, 16, 32, 64
@@ -72,6 +73,7 @@ SYMBOLS = [
     ("bgamd_td_apply", C.c_int, [_P, _P, _P]),
     ("bgamd_td_replay", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_double, C.c_float, _P]),
     ("bgamd_td_stats", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("bgamd_td_active_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("bgamd_td_time", C.c_int, [_P, C.c_int]),
     ("bgamd_td_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]

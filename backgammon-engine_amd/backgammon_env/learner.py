@@ -157,6 +157,12 @@ class DeviceTDLambdaLearner:
     def time_trace_kernel(self, enable=True):
         self._capi.check(self._lib.bgamd_td_time(self._h, 1 if enable else 0), "td_time")
 
+    def active_columns(self):
+        """Σ over the (game, step) updates of the last replay (the last sub-round) of the W1 trace columns touched (of 198)."""
+        c = self._C.c_uint64()
+        self._capi.check(self._lib.bgamd_td_active_columns(self._h, self._C.byref(c)), "td_active_columns")
+        return int(c.value)
+
     def trace_kernel_times(self):
         C = self._C
         ms, n, gs = C.c_double(), C.c_uint64(), C.c_uint64()

@@ -419,6 +419,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     constexpr float NL2E = -1.44269504088896340736f;
     uint32_t n_delta = 0;
     bool list_overflow = false;
+#ifdef BG_EVAL_STAGGER
+    // experiment: de-phase the four waves of a SIMD (waves w, w+4, w+8, w+12 share one) by a quarter tile each
+    for (int k = 0; k < (int)(threadIdx.x >> 8) * BG_EVAL_STAGGER; ++k) __builtin_amdgcn_s_sleep(8);
+#endif
 
     // software pipeline: the next tile's row + info are in flight while this tile is computed
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
@@ -452,6 +456,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         uint16_t *lst = sList + lane;
 #pragma unroll
         for (int e = 0; e < DELTA_MAX; ++e) lst[e * 64] = 0;       // entry 0 = "add 0 x row 0": the apply loop reads blindly
+#if defined(BG_ABL) && (BG_ABL & 1)
+        if (p[0] == 0xFFFFFFFFu)                                    // ablation: no list construction (never true)
+#endif
+        {
 #define BG_PUSH(F, TYPE, M)                                                                          \
     {                                                                                                \
         if (cnt < DELTA_MAX) lst[cnt * 64] = (uint16_t)((uint32_t)(F) | ((uint32_t)(((TYPE) == 1 ? 1 : 2) * (M)) & 255u) << 8); \
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 BG_PUSH(delta_row(sd == 0 ? 196 : 195), sd == 0 ? 2 : 1, d);
             }
         }
+        }
 #undef BG_PUSH
         // A legal turn changes at most 13 features (4 origins + 4 landing points of the mover, 4 hit points + the bar
         // counter of the opponent; test_delta_list_worst_case builds that turn).  More than DELTA_MAX means the row is
@@ -502,6 +511,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
             const uint32_t t = maxcnt | (1u << b);
             if (__ballot(cnt >= t) != 0ull) maxcnt = t;
         }
+#if defined(BG_ABL) && (BG_ABL & 2)
+        maxcnt = maxcnt > 100 ? 1 : 0;                             // ablation: no gathers
+#endif
         __builtin_amdgcn_wave_barrier();
 
         // ---- 64 hidden units at a time (two halves of 32 pairs): root term, a += Δ · W1[:, f] over the lane's entries (a
@@ -529,18 +541,24 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 ent = nent;
             }
             // hidden sigmoids two units at a time: the "1 +" and the "· W2, +=" are packed fp32 operations
+#if defined(BG_ABL) && (BG_ABL & 4)
+#define BG_SIGP(A, W, S) __builtin_elementwise_fma(W, A, S)       /* ablation: no transcendentals */
+#else
+#define BG_SIGP(A, W, S) delta_sigmoid_pair(A, W, S)
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4_t w = w2v[16 * c + j];
-                sum2 = delta_sigmoid_pair(a[2 * j], w.lo, sum2);
-                sum2 = delta_sigmoid_pair(a[2 * j + 1], w.hi, sum2);
+                sum2 = BG_SIGP(a[2 * j], w.lo, sum2);
+                sum2 = BG_SIGP(a[2 * j + 1], w.hi, sum2);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4_t w = w2v[16 * c + 8 + j];
-                sum2 = delta_sigmoid_pair(a2[2 * j], w.lo, sum2);
-                sum2 = delta_sigmoid_pair(a2[2 * j + 1], w.hi, sum2);
+                sum2 = BG_SIGP(a2[2 * j], w.lo, sum2);
+                sum2 = BG_SIGP(a2[2 * j + 1], w.hi, sum2);
             }
+#undef BG_SIGP
         }
         const float sum = sum2.x + sum2.y;
         __builtin_amdgcn_wave_barrier();
@@ -739,9 +757,30 @@ inline void relayout_w1_bf16x3(const float *w1, uint16_t *wl)
                 }
 }
 
-__global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
-    const uint4 *__restrict__ rows, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
-    const float *__restrict__ b1, float *__restrict__ hidden)
+// where a tile row comes from: the env's root rows (row R = game R) ...
+struct RootRowsFetch {
+    const uint4 *rows;
+    __device__ __forceinline__ bool get(long long R, uint4 &u0, uint4 &u1) const { u0 = rows[2 * R]; u1 = rows[2 * R + 1]; return true; }
+};
+// ... or the learner's trajectory log: row R = state s_{t + (R & 1)} of the game at order position R >> 1 (gmeta = lane,
+// length); a state past the game's end is an all-zero row (its value is never used: train.py:165-166)
+struct TrajRowsFetch {
+    const uint4 *rows; const int4 *gmeta; long long t, n_lanes, T;
+    __device__ __forceinline__ bool get(long long R, uint4 &u0, uint4 &u1) const
+    {
+        const int4 gm = gmeta[R >> 1];
+        const long long tt = t + (R & 1);
+        if (tt >= gm.y || tt >= T) return false;
+        const uint4 *src = rows + (tt * n_lanes + gm.x) * 2;
+        u0 = src[0]; u1 = src[1];
+        return true;
+    }
+};
+
+// OUT_SCALE: the factor on (W1 x + b1) in the output: -log2(e) for the incremental evaluator, 1 for the learner
+template <class Fetch, bool LOG2E_SCALE>
+__device__ __forceinline__ void root3_body(const Fetch fetch, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
+                                           const float *__restrict__ b1, float *__restrict__ hidden)
 {
     extern __shared__ uint4 sW3[];                          // [3][ROOT3_PHASE_STEPS][4][64]
     uint2 *sLut = reinterpret_cast<uint2 *>(sW3 + 3 * ROOT3_PHASE_STEPS * 4 * 64);
@@ -758,9 +797,13 @@ __global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
         const long long tile = base + wave;
         const bool has = tile < n_tiles;
         uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool row_ok = false;
         if (has && tile * 32 + r < n_rows) {
-            const uint4 u0 = rows[2 * (tile * 32 + r)], u1 = rows[2 * (tile * 32 + r) + 1];
-            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+            uint4 u0, u1;
+            if (fetch.get(tile * 32 + r, u0, u1)) {
+                row_ok = true;
+                p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+            }
         }
         const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
         floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
@@ -785,7 +828,7 @@ __global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
                         a.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
                     } else {                                 // features 192..197 on the h == 0 lanes; off counts as integers
                         const int turn = (p[0] & TURN_BIT) ? 1 : 0;
-                        const uint32_t t0 = turn == 0 ? 0x3F80u : 0u, t1 = turn == 0 ? 0u : 0x3F80u;
+                        const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
                         const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
                         const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
                         a.u = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
@@ -812,11 +855,46 @@ __global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
                 const long long orow = tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
                 if (orow < n_rows) {
                     float *o = hidden + orow * N_HID + r;
-                    o[0] = NL2E * (acc0[j] + bb[0]); o[32] = NL2E * (acc1[j] + bb[1]);
-                    o[64] = NL2E * (acc2[j] + bb[2]); o[96] = NL2E * (acc3[j] + bb[3]);
+                    constexpr float SC = LOG2E_SCALE ? NL2E : 1.0f;
+                    o[0] = SC * (acc0[j] + bb[0]); o[32] = SC * (acc1[j] + bb[1]);
+                    o[64] = SC * (acc2[j] + bb[2]); o[96] = SC * (acc3[j] + bb[3]);
                 }
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
+    const uint4 *__restrict__ rows, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
+    const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    root3_body<RootRowsFetch, true>(RootRowsFetch{rows}, n_rows, wl3, lut, b1, hidden);
+}
+
+// the learner's forward pass: plain W1 x + b1 for s_t and s_{t+1} of every running game (row 2 i + s), bg_learner.h
+__global__ __launch_bounds__(ROOT3_THREADS) void traj_hidden_bf16x3_kernel(
+    const uint4 *__restrict__ rows, const int4 *__restrict__ gmeta, long long t, long long n_lanes, long long T, long long n_rows,
+    const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut, const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    root3_body<TrajRowsFetch, false>(TrajRowsFetch{rows, gmeta, t, n_lanes, T}, n_rows, wl3, lut, b1, hidden);
+}
+
+// position of W1[n][f] in ONE bf16 plane of the root3 layout (relayout_w1_bf16x3), in 16-bit units
+__host__ __device__ __forceinline__ int root3_plane_index(int n, int f)
+{
+    const int s = f < 192 ? (f >> 4) : 12, lh = f < 192 ? ((f >> 3) & 1) : 0, jj = f < 192 ? (f & 7) : f - 192;
+    return (((s * 4 + (n >> 5)) * 64) + (n & 31) + 32 * lh) * 8 + jj;
+}
+// W1[n][f] -> its three bf16 terms, stored into the three planes (the learner refreshes them after every update)
+__device__ __forceinline__ void root3_store_weight(uint16_t *__restrict__ wl3, int n, int f, float w)
+{
+    if (f >= 196) w = w / 15.0f;
+    const int o = root3_plane_index(n, f);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const uint16_t b = f32_to_bf16_rne(w);
+        w -= __uint_as_float((uint32_t)b << 16);                  // exact: the residual fits fp32
+        wl3[(size_t)part * ROOT3_PART_U4 * 8 + o] = b;
     }
 }
 

@@ -15,7 +15,15 @@
 //   td_reduce_kernel   Σ over game groups -> the 25 601-float update; θ += update (or hand it to the caller for
 //                      the one all-reduce of the step), W1 re-transposed for the next forward
 //
-// Algorithmic bytes per (game, step): 2 · 25 601 · 4 = 204 808 B of trace traffic (SURVEY §8d "learner").
+// Algorithmic bytes per (game, step): 2 · 25 601 · 4 = 204 808 B of trace traffic (SURVEY §8d "learner") for DENSE traces.
+//
+// Column-sparse traces (what runs): ∇W1 = db1 ⊗ x is zero in every column whose feature x_j is zero, and the encoder is
+// sparse (<= 35 of 198 features are non-zero), so the W1 part of a game's trace is EXACTLY zero in the columns of the
+// features that have never been non-zero in that game so far -- 63 % of them, averaged over the turns of a greedy game
+// (89 of 198 features have been active by the end of one).  The trace is stored feature-major (column j = 128 contiguous
+// floats), every game carries the bit mask of its ever-active features, and the pass touches only those columns: λ·0 + 0 is
+// never read, never computed, never written.  Same arithmetic on the same numbers in the same order: results are
+// bit-identical to the dense pass (BGAMD_TD_DENSE=1 keeps it for the test that says so), at ~0.37 of its HBM traffic.
 #pragma once
 #include "bg_board.h"
 #include "bg_eval.h"
@@ -29,8 +37,19 @@ constexpr int TD_OFF_B1 = 25344, TD_OFF_W2 = 25472, TD_OFF_B2 = 25600;
 constexpr int TD_F_ONE = 198, TD_F_ZERO = 199, TD_F_DB1 = 200, TD_F_GH = 328, TD_F_G = 456, TD_FLD = 464;
 constexpr int TD_TRACE_THREADS = 256;
 constexpr int TD_SLICES = (TD_LD / 4 + TD_TRACE_THREADS - 1) / TD_TRACE_THREADS;   // 26
-constexpr int TD_CHUNK = 8;              // games staged in LDS at a time by the trace kernel
+#ifndef BG_TD_CHUNK
+#define BG_TD_CHUNK 8
+#endif
+constexpr int TD_CHUNK = BG_TD_CHUNK;    // games staged in LDS at a time by the trace kernel
 constexpr int TD_MAX_GROUPS = 256;
+constexpr int TD_MASK_WORDS = 8;         // 198 feature bits in 7 words, padded to 32 B per game
+// INTERNAL order of a trace row / partial-sum row (the parameter order of theta is fc1.weight[n][j] | b1 | W2 | b2):
+//   [j * 128 + n] = W1[n][j] for j < 198 (feature-major: a column of W1 is 512 contiguous bytes), then b1, W2, b2 at the
+//   same offsets as in parameter order
+__host__ __device__ __forceinline__ int td_param_of_internal(int p)
+{
+    return p < TD_OFF_B1 ? (p & (N_HID - 1)) * N_IN + (p >> 7) : p;
+}
 
 struct TdView {
     float *theta;                        // [TD_LD] flat parameters
@@ -45,6 +64,13 @@ struct TdView {
     const int32_t *length;               // [n_lanes]
     const uint8_t *p1_won;               // [n_lanes]
     int4 *gmeta;                         // [max_games] (lane, length, p1_won, 0) by order position: one load, no chain
+    uint16_t *wl3;                       // fc1.weight as three bf16 planes in the MFMA layout of bg_eval.h (refreshed with every update)
+    uint2 *lut;                          // count -> 4 bf16 features
+    float *hid;                          // [2 * max_games][128] W1 x + b1 of (s_t, s_{t+1}) per running game, from the MFMA pass
+    uint32_t *amask;                     // [max_games][TD_MASK_WORDS] features that have been non-zero in the game so far
+    uint32_t *anew;                      // [max_games][TD_MASK_WORDS] ... for the first time at the current step (trace column = 0: not read)
+    unsigned long long *act_cols;        // Σ over (game, step) of active W1 trace columns since begin (traffic report)
+    int dense;                           // BGAMD_TD_DENSE=1: every column active from the first step (the dense pass)
     long long T, n_lanes, n_games;
 };
 
@@ -65,9 +91,13 @@ __global__ void td_gather_kernel(TdView v)
 
 // TD_GB games x {s_t, s_{t+1}} per workgroup of 128 threads (2 for small rounds: a shorter FMA chain per thread and
 // more workgroups; 4 for large ones: half the W1 traffic)
-template <int TD_GB>
+// PRE = false: the whole forward pass on the VALUs (small rounds: one launch, latency is what counts).
+// PRE = true : the hidden pre-activations W1 x + b1 come from traj_hidden_bf16x3_kernel (bg_eval.h: exact bf16 x 3 split of
+//              W1 on the matrix pipe, the [2 G x 198] · [198 x 128] product of the step); this kernel is its epilogue.
+template <int TD_GB, bool PRE>
 __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
 {
+    __shared__ unsigned int s_cols;
     constexpr int NR = 2 * TD_GB;                         // rows: [s][game]
     __shared__ __attribute__((aligned(16))) float xs[N_IN][NR];
     __shared__ float hs[NR][N_HID + 1];
@@ -77,9 +107,11 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
     const long long i0 = (long long)blockIdx.x * TD_GB;
     // this thread's fc1.weight column set (198 values) is fetched in ONE batch of independent loads -- a single L2
     // round trip instead of a chain of them -- and the FMAs then run out of registers
-    float w[N_IN];
+    float w[PRE ? 1 : N_IN];
+    if (!PRE) {
 #pragma unroll
-    for (int j = 0; j < N_IN; ++j) w[j] = v.w1t[j * N_HID + tid];
+        for (int j = 0; j < N_IN; ++j) w[j] = v.w1t[j * N_HID + tid];
+    }
 
     // ---- decode: thread = (row r, chunk c): board points c, c + CH, ... ----
     constexpr int CH = 128 / NR;                          // chunks (threads per row)
@@ -124,26 +156,52 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
             xs[197][r] = (float)count_at(sd[1], 0) / 15.0f;
         }
     }
+    if (tid == 0) s_cols = 0;
     __syncthreads();
+    // ---- ever-active feature masks of the games (thread = (game, word)): the trace pass touches only these columns ----
+    if (tid < TD_GB * TD_MASK_WORDS) {
+        const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
+        const long long i = i0 + g;
+        if (i < n_active) {
+            uint32_t now = 0;
+#pragma unroll 8
+            for (int b = 0; b < 32; ++b) {
+                const int j = 32 * wd + b;
+                if (j < N_IN && xs[j][g] != 0.0f) now |= 1u << b;          // row g = state s_t of game g
+            }
+            const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);     // 198 = 6 * 32 + 6
+            if (v.dense) now = valid;
+            const uint32_t old = t == 0 ? 0u : v.amask[i * TD_MASK_WORDS + wd];
+            v.amask[i * TD_MASK_WORDS + wd] = old | now;
+            v.anew[i * TD_MASK_WORDS + wd] = now & ~old;
+            atomicAdd(&s_cols, (unsigned int)__popc(old | now));
+        }
+    }
 
     // ---- hidden layer: thread n owns unit n for all 16 rows ----
     const int n = tid;
     float acc[NR];
-    {
+    if (PRE) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                         // row r = [s][game] here, row 2 i + s in the MFMA pass's output
+            const long long i = i0 + (r % TD_GB);
+            acc[r] = i < n_active ? v.hid[(2 * i + r / TD_GB) * N_HID + n] : 0.0f;
+        }
+    } else {
         const float b = v.theta[TD_OFF_B1 + n];
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[r] = b;
-    }
 #pragma unroll
-    for (int j = 0; j < N_IN; ++j) {
-        const float4 *xr = reinterpret_cast<const float4 *>(&xs[j][0]);
+        for (int j = 0; j < N_IN; ++j) {
+            const float4 *xr = reinterpret_cast<const float4 *>(&xs[j][0]);
 #pragma unroll
-        for (int q = 0; q < NR / 4; ++q) {
-            const float4 x4 = xr[q];
-            acc[4 * q + 0] = fmaf(w[j], x4.x, acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(w[j], x4.y, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(w[j], x4.z, acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(w[j], x4.w, acc[4 * q + 3]);
+            for (int q = 0; q < NR / 4; ++q) {
+                const float4 x4 = xr[q];
+                acc[4 * q + 0] = fmaf(w[PRE ? 0 : j], x4.x, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(w[PRE ? 0 : j], x4.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(w[PRE ? 0 : j], x4.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(w[PRE ? 0 : j], x4.w, acc[4 * q + 3]);
+            }
         }
     }
     const float w2 = v.theta[TD_OFF_W2 + n];
@@ -194,27 +252,41 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         if (n + 128 < N_IN) f[n + 128] = xs[n + 128][gq];
         if (n == 0) { f[TD_F_ONE] = 1.0f; f[TD_F_ZERO] = 0.0f; f[TD_F_G] = g; }
     }
+    if (tid == 0 && s_cols) atomicAdd(v.act_cols, (unsigned long long)s_cols);     // (the barriers above ordered the LDS adds)
 }
 
-// grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace; `ng` games per group
+// grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace (internal order); `ng` games per group.
+// A thread owns four consecutive internal positions = ONE feature column j and four hidden units of it (or four of the
+// dense tail b1 | W2 | b2), for every game of its group: a W1 column that is not active in a game is skipped for that game
+// (no load, no store, nothing to add), one that became active at this step is written without being read.
 template <bool FIRST>
 __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, long long n_active, int ng, float lambda)
 {
-    __shared__ float fs[TD_CHUNK][TD_FLD];
+    // what a slice needs of a game's factor row: the 8 features of its 1 024 positions (x[jb .. jb+7]; for the last slices
+    // that window is x[192..197] | 1 | 0), and db1 | g·h | g
+    constexpr int L_X = 0, L_DB1 = 8, L_GH = L_DB1 + N_HID, L_G = L_GH + N_HID, L_LD = 268;
+    __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][L_LD];
     __shared__ float cs[TD_CHUNK];
+    __shared__ uint32_t ms[TD_CHUNK][TD_MASK_WORDS], ns[TD_CHUNK][TD_MASK_WORDS];
+    const int jb = blockIdx.x * 8 < 192 ? blockIdx.x * 8 : 192;
     const int tid = threadIdx.x;
     const int p0 = (blockIdx.x * TD_TRACE_THREADS + tid) * 4;
     const bool in_row = p0 < TD_LD;
+    const bool is_w1 = p0 < TD_OFF_B1;
+    const int jw = is_w1 ? (p0 >> 7) : 0;                     // feature column of a W1 thread
+    const int mword = jw >> 5;
+    const uint32_t mbit = 1u << (jw & 31);
     const long long g0 = (long long)blockIdx.y * ng;
     int ia[4], ib[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = p0 + k;
-        if (p < TD_OFF_B1) { const int n = p / N_IN; ia[k] = TD_F_DB1 + n; ib[k] = p - n * N_IN; }
-        else if (p < TD_OFF_W2) { ia[k] = TD_F_DB1 + (p - TD_OFF_B1); ib[k] = TD_F_ONE; }
-        else if (p < TD_OFF_B2) { ia[k] = TD_F_GH + (p - TD_OFF_W2); ib[k] = TD_F_ONE; }
-        else if (p == TD_OFF_B2) { ia[k] = TD_F_G; ib[k] = TD_F_ONE; }
-        else { ia[k] = TD_F_ZERO; ib[k] = TD_F_ZERO; }
+        constexpr int ONE = L_X + (TD_F_ONE - 192), ZERO = L_X + (TD_F_ZERO - 192);     // in the window of the last slices
+        if (p < TD_OFF_B1) { ia[k] = L_DB1 + (p & (N_HID - 1)); ib[k] = L_X + (p >> 7) - jb; }
+        else if (p < TD_OFF_W2) { ia[k] = L_DB1 + (p - TD_OFF_B1); ib[k] = ONE; }
+        else if (p < TD_OFF_B2) { ia[k] = L_GH + (p - TD_OFF_W2); ib[k] = ONE; }
+        else if (p == TD_OFF_B2) { ia[k] = L_G; ib[k] = ONE; }
+        else { ia[k] = ZERO; ib[k] = ZERO; }
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < ng; c += TD_CHUNK) {
@@ -225,40 +297,57 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
         const int m = left < TD_CHUNK ? (int)left : TD_CHUNK;
         __syncthreads();
         {
-            const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
-            float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
-            for (int q = tid; q < m * (TD_FLD / 4); q += TD_TRACE_THREADS) dst[q] = src[q];
+            constexpr int ROW4 = L_LD / 4;                       // 67 float4 per game: 2 of the x window, 65 of db1 | g·h | g
+            for (int q = tid; q < m * ROW4; q += TD_TRACE_THREADS) {
+                const int gq = q / ROW4, c4 = q - gq * ROW4;
+                const float *f = v.fac + (gb + gq) * TD_FLD;
+                reinterpret_cast<float4 *>(&fs[gq][0])[c4] =
+                    *reinterpret_cast<const float4 *>(c4 < 2 ? f + jb + 4 * c4 : f + TD_F_DB1 + 4 * (c4 - 2));
+            }
             if (tid < m) cs[tid] = v.coef[gb + tid];
+            if (tid < m * TD_MASK_WORDS) {
+                (&ms[0][0])[tid] = v.amask[gb * TD_MASK_WORDS + tid];
+                (&ns[0][0])[tid] = v.anew[gb * TD_MASK_WORDS + tid];
+            }
         }
-        // the trace loads of the whole chunk go out before the first use
-        td_f32x4 ev[TD_CHUNK];
-        if (!FIRST && in_row) {
+        __syncthreads();
+        // which of the chunk's games this thread's column exists in, and where it has to be read: the loads of the whole
+        // chunk go out before the first use
+        uint32_t act = 0, rd = 0;
+        if (in_row) {
 #pragma unroll
             for (int q = 0; q < TD_CHUNK; ++q)
                 if (q < m) {
-                    const td_f32x4 *ep = reinterpret_cast<const td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
-                    ev[q] = __builtin_nontemporal_load(ep);
+                    const bool a = !is_w1 || (ms[q][mword] & mbit);
+                    const bool fresh = FIRST || (is_w1 && (ns[q][mword] & mbit));
+                    act |= (a ? 1u : 0u) << q;
+                    rd |= ((a && !fresh) ? 1u : 0u) << q;
                 }
         }
-        __syncthreads();
-        if (in_row) {
+        td_f32x4 ev[TD_CHUNK];
 #pragma unroll
-            for (int q = 0; q < TD_CHUNK; ++q) {
-                if (q < m) {
-                    td_f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                    if (!FIRST) x = ev[q];
-                    x.x = fmaf(lambda, x.x, fs[q][ia[0]] * fs[q][ib[0]]);
-                    x.y = fmaf(lambda, x.y, fs[q][ia[1]] * fs[q][ib[1]]);
-                    x.z = fmaf(lambda, x.z, fs[q][ia[2]] * fs[q][ib[2]]);
-                    x.w = fmaf(lambda, x.w, fs[q][ia[3]] * fs[q][ib[3]]);
-                    td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
-                    __builtin_nontemporal_store(x, ep);
-                    const float cf = cs[q];
-                    acc.x = fmaf(cf, x.x, acc.x);
-                    acc.y = fmaf(cf, x.y, acc.y);
-                    acc.z = fmaf(cf, x.z, acc.z);
-                    acc.w = fmaf(cf, x.w, acc.w);
-                }
+        for (int q = 0; q < TD_CHUNK; ++q) {
+            ev[q] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((rd >> q) & 1u) {
+                const td_f32x4 *ep = reinterpret_cast<const td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
+                ev[q] = __builtin_nontemporal_load(ep);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TD_CHUNK; ++q) {
+            if ((act >> q) & 1u) {
+                td_f32x4 x = ev[q];
+                x.x = fmaf(lambda, x.x, fs[q][ia[0]] * fs[q][ib[0]]);
+                x.y = fmaf(lambda, x.y, fs[q][ia[1]] * fs[q][ib[1]]);
+                x.z = fmaf(lambda, x.z, fs[q][ia[2]] * fs[q][ib[2]]);
+                x.w = fmaf(lambda, x.w, fs[q][ia[3]] * fs[q][ib[3]]);
+                td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
+                __builtin_nontemporal_store(x, ep);
+                const float cf = cs[q];
+                acc.x = fmaf(cf, x.x, acc.x);
+                acc.y = fmaf(cf, x.y, acc.y);
+                acc.z = fmaf(cf, x.z, acc.z);
+                acc.w = fmaf(cf, x.w, acc.w);
             }
         }
     }
@@ -270,21 +359,25 @@ __global__ __launch_bounds__(256) void td_reduce_kernel(TdView v, int n_groups, 
 {
     __shared__ float red[4][64];
     const int pi = threadIdx.x & 63, gl = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + pi;
+    const int q = blockIdx.x * 64 + pi;                      // INTERNAL position (the partial sums' order)
     float s = 0.0f;
-    if (p < TD_P) {
+    if (q < TD_P) {
 #pragma unroll 8
-        for (int g = gl; g < n_groups; g += 4) s += v.partial[(long long)g * TD_LD + p];
+        for (int g = gl; g < n_groups; g += 4) s += v.partial[(long long)g * TD_LD + q];
     }
     red[gl][pi] = s;
     __syncthreads();
-    if (gl == 0 && p < TD_P) {
+    if (gl == 0 && q < TD_P) {
         const float u = (red[0][pi] + red[1][pi]) + (red[2][pi] + red[3][pi]);
+        const int p = td_param_of_internal(q);               // parameter order of theta / the update handed out
         if (upd) upd[p] = u;
         if (apply) {
             const float th = v.theta[p] + u;
             v.theta[p] = th;
-            if (p < TD_OFF_B1) { const int n = p / N_IN, j = p - n * N_IN; v.w1t[j * N_HID + n] = th; }
+            if (q < TD_OFF_B1) {
+                v.w1t[q] = th;                               // w1t is [j][n]: the internal order of the W1 block
+                root3_store_weight(v.wl3, q & (N_HID - 1), q >> 7, th);
+            }
         }
     }
 }
@@ -296,7 +389,11 @@ __global__ void td_apply_kernel(TdView v, const float *upd, int set)
     if (p >= TD_P) return;
     const float th = set ? upd[p] : v.theta[p] + upd[p];
     v.theta[p] = th;
-    if (p < TD_OFF_B1) { const int n = p / N_IN, j = p - n * N_IN; v.w1t[j * N_HID + n] = th; }
+    if (p < TD_OFF_B1) {
+        const int n = p / N_IN, j = p - n * N_IN;
+        v.w1t[j * N_HID + n] = th;
+        root3_store_weight(v.wl3, n, j, th);
+    }
 }
 
 }  // namespace bg

@@ -1419,6 +1419,8 @@ struct bgamd_td {
     long long max_games = 0;
     TdView v{};
     bool has_weights = false, begun = false;
+    int n_cu = 256;
+    long long mfma_min = 3072;             // running games from which the forward pass goes to the matrix pipe (BGAMD_TD_MFMA_MIN)
     uint64_t updates = 0;
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -1470,7 +1472,26 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.sq, (size_t)max_games * 8);
     TDALLOC(v.gmeta, (size_t)max_games * 16);
     TDALLOC(v.partial, (size_t)TD_MAX_GROUPS * TD_LD * 4);
+    TDALLOC(v.amask, (size_t)max_games * TD_MASK_WORDS * 4);
+    TDALLOC(v.anew, (size_t)max_games * TD_MASK_WORDS * 4);
+    TDALLOC(v.act_cols, 8);
+    TDALLOC(v.wl3, 3 * EVAL16_W_BYTES);
+    TDALLOC(v.lut, EVAL16_LUT_BYTES);
+    TDALLOC(v.hid, (size_t)max_games * 2 * N_HID * 4);
 #undef TDALLOC
+    {
+        uint32_t lut[32];
+        make_count_lut(lut);
+        HIPCHK(hipMemcpy(v.lut, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(v.wl3, 0, 3 * EVAL16_W_BYTES));          // the padding lanes of the tail K-step stay zero
+        HIPCHK(hipFuncSetAttribute((const void *)traj_hidden_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROOT3_LDS_TOTAL));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        td->n_cu = prop.multiProcessorCount;
+        td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 3072;
+    }
+    v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
+    HIPCHK(hipMemset(v.act_cols, 0, 8));
     HIPCHK(hipMemset(v.theta, 0, TD_LD * 4));
     HIPCHK(hipMemset(v.sq, 0, (size_t)max_games * 8));
     *out = td;
@@ -1483,7 +1504,7 @@ int bgamd_td_destroy(bgamd_td *td)
     hipSetDevice(td->device);
     hipDeviceSynchronize();
     TdView &v = td->v;
-    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta};
+    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wl3, v.lut, v.hid};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
     delete td;
@@ -1526,6 +1547,7 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
         hipLaunchKernelGGL(td_gather_kernel, grid1(n_games, 256), dim3(256), 0, (hipStream_t)stream, v);
         HIPCHK(hipGetLastError());
     }
+    HIPCHK(hipMemsetAsync(v.act_cols, 0, 8, (hipStream_t)stream));
     td->updates = 0;
     td->begun = true;
     return BGAMD_OK;
@@ -1542,10 +1564,20 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         return BGAMD_OK;
     }
     const TdView &v = td->v;
-    if (n_active <= 8192)
-        hipLaunchKernelGGL(td_forward_kernel<2>, grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+    if (n_active >= td->mfma_min) {
+        // the [2 G x 198] · [198 x 128] product of the step on the matrix pipe (exact bf16 x 3 split of fc1.weight, fp32
+        // accumulation: the env's root pass), then the epilogue per game
+        const long long n_rows = 2 * n_active;
+        long long blocks = ((n_rows + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
+        if (blocks > td->n_cu) blocks = td->n_cu;
+        hipLaunchKernelGGL(traj_hidden_bf16x3_kernel, dim3((unsigned)blocks), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s, v.rows,
+                           (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
+                           (const float *)(v.theta + TD_OFF_B1), v.hid);
+        hipLaunchKernelGGL((td_forward_kernel<4, true>), grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+    } else if (n_active <= 8192)
+        hipLaunchKernelGGL((td_forward_kernel<2, false>), grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     else
-        hipLaunchKernelGGL(td_forward_kernel<4>, grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+        hipLaunchKernelGGL((td_forward_kernel<4, false>), grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     // games per group: >= 4, and at most TD_MAX_GROUPS groups
     long long ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
     if (ng < 4) ng = 4;
@@ -1612,6 +1644,17 @@ int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
         *h_sq_sum = acc;
     }
     if (h_updates) *h_updates = (int64_t)td->updates;
+    return BGAMD_OK;
+}
+
+int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns)
+{
+    if (!td || !h_columns) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpy(&c, td->v.act_cols, 8, hipMemcpyDeviceToHost));
+    *h_columns = (uint64_t)c;
     return BGAMD_OK;
 }
 

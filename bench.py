@@ -53,7 +53,23 @@ def host_description():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+    quota = None                                   # a container's CPU share (cgroup v2 cpu.max / v1 cfs quota) caps what threads can use
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        usable = max(1, min(usable, int(round(quota))))
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable,
+            "cgroup_cpu_quota": round(quota, 2) if quota else None}
 
 
 def cpu_baseline(weights, budget_s=10.0):
@@ -156,6 +172,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes and the CPU baseline, sample U on fewer lanes")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -246,10 +263,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    u_step, c_step = distinct_ratio(env, prec)
+    u_step, c_step = distinct_ratio(env, prec, samples=1 if a.quick else 4)
     # the other value-net modes on the same env (untimed region of the contract: extra information only)
     alt = {}
-    if world == 1:
+    if world == 1 and not a.quick:
         for name, pm in (("f32", bg.F32), ("f32_dense", bg.F32_DENSE), ("f16x2", bg.F16X2), ("bf16", bg.BF16)):
             if name == a.precision:
                 continue
@@ -370,7 +387,7 @@ def main():
                               gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
     if alt:
         out["alt_modes"] = alt
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not a.quick:
         out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)
     if use_dist:

@@ -241,6 +241,10 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
 int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream);
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream);
 int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates);
+/* Traffic report of the column-sparse traces: Σ over the (game, step) updates since begin of the W1 trace columns that
+ * were touched (of 198; a column = 128 floats, read + written).  BGAMD_TD_DENSE=1 in the environment at bgamd_td_create
+ * keeps every column active (the dense pass: same results bit for bit, 198 columns per update).  Synchronises. */
+int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns);
 /* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1) */
 int bgamd_td_time(bgamd_td *td, int enable);
 int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps);

@@ -491,3 +491,34 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
     assert c.tryMove(p2, 1, 6, 5)[0] and game.getGameBoard() == START and c.getGameBoard() != START
     print("Game.clone(): %.2f ms each while the pool fills, %.3f ms from the pool" % (1e3 * dt_first / 50, 1e3 * dt_pool))
     assert dt_pool < 0.01
+
+
+def test_sparse_traces_equal_dense_traces_bit_for_bit(bg, weights):
+    """The learner touches only the W1 trace columns of features that have been non-zero in a game so far (the others
+    are exactly zero).  BGAMD_TD_DENSE=1 makes every column active from the first step -- the dense pass.  Same log,
+    same hyper-parameters: identical weights bit for bit, identical TD errors, ~0.4 of the columns touched."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
+    n = 3000
+    env = bg.VecGame(n, seed=2025)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    lengths = lengths.clone()
+    lengths[::11] = 0
+    out = {}
+    for mode in ("sparse", "dense"):
+        if mode == "dense":
+            os.environ["BGAMD_TD_DENSE"] = "1"
+        try:
+            L = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+        finally:
+            os.environ.pop("BGAMD_TD_DENSE", None)
+        sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=0.01)
+        out[mode] = (_np(L.theta), sq, cnt, L.active_columns())
+        sq2, cnt2 = L.replay_rows(rows, lengths, p1_won, batch_scale=0.01, split_apply=True)     # second replay on used buffers
+        out[mode + "2"] = (_np(L.theta), sq2, cnt2)
+    assert np.array_equal(out["sparse"][0], out["dense"][0]) and out["sparse"][1] == out["dense"][1]
+    assert np.array_equal(out["sparse2"][0], out["dense2"][0])
+    assert out["dense"][3] == 198 * out["dense"][2]
+    frac = out["sparse"][3] / out["dense"][3]
+    print("active W1 trace columns: %.3f of the dense pass" % frac)
+    assert 0.2 < frac < 0.6 and np.abs(out["sparse"][0] - weights).max() > 1e-4
