@@ -286,13 +286,23 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
 // Lane = row, 32 hidden units at a time in registers, W1^T in LDS (132-float row stride), each lane's (row, Δ) list in LDS.
 // The sum is the same real number as the dense chain with a different association: values agree to ~1e-7.
 constexpr int DELTA_THREADS = 1024;                     // 16 waves per CU, one workgroup per CU (LDS: W1^T + the lists)
-constexpr int DW_STRIDE = 132;                          // floats per feature row of W1^T in LDS
+#ifndef BG_DW_STRIDE
+#define BG_DW_STRIDE 132
+#endif
+constexpr int DW_STRIDE = BG_DW_STRIDE;                 // floats per feature row of W1^T in LDS
 // Row of feature f in the LDS table: 9 * point + (4 * side + level) for the board features, 216.. for the tail.  The
 // LDS bank class of a 16-byte read is (row + chunk) mod 8; candidates of one game mostly differ in WHICH point a
 // checker left or reached at the same thermometer level, and with row = f (= 8 * point + level) all those lanes
 // hit the same banks (measured: half of all LDS cycles were conflict cycles).  9 * point spreads them.
+#if defined(BG_ROW_LAYOUT) && BG_ROW_LAYOUT == 1            // experiment: level-major rows
+constexpr int DW_ROWS = 198;
+__host__ __device__ constexpr int delta_row(int f) { return f < 192 ? (f >> 3) + 24 * (f & 7) : f; }
+__host__ __device__ constexpr int delta_row_board(int point, int k8) { return point + 24 * k8; }
+#else
 constexpr int DW_ROWS = 9 * 24 + 6;                     // 222
 __host__ __device__ constexpr int delta_row(int f) { return f < 192 ? 9 * (f >> 3) + (f & 7) : 216 + (f - 192); }
+__host__ __device__ constexpr int delta_row_board(int point, int k8) { return 9 * point + k8; }     // board features: no range test
+#endif
 constexpr int DELTA_W_FLOATS = DW_ROWS * DW_STRIDE;     // 29 304
 constexpr int DELTA_MAX = 16;                           // <= 4 moves x (origin, destination, hit point, bar)
 constexpr int DELTA_LDS_TOTAL = (DELTA_W_FLOATS + N_HID) * 4 + (DELTA_THREADS / 64) * DELTA_MAX * 64 * 2;   // 16-bit list entries
@@ -419,10 +429,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     constexpr float NL2E = -1.44269504088896340736f;
     uint32_t n_delta = 0;
     bool list_overflow = false;
-#ifdef BG_EVAL_STAGGER
-    // experiment: de-phase the four waves of a SIMD (waves w, w+4, w+8, w+12 share one) by a quarter tile each
-    for (int k = 0; k < (int)(threadIdx.x >> 8) * BG_EVAL_STAGGER; ++k) __builtin_amdgcn_s_sleep(8);
-#endif
 
     // software pipeline: the next tile's row + info are in flight while this tile is computed
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 uint32_t x = (ge_new[k] ^ ge_old[k]) & PTS;
                 while (x) {
                     const int pos = __ffs(x) - 1; x &= x - 1;
-                    BG_PUSH(9 * (pos - 1) + 4 * sd + k, 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
+                    BG_PUSH(delta_row_board(pos - 1, 4 * sd + k), 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
                 }
             }
             uint32_t x4 = diff & PTS & ((b2 | b3) | (c2 | c3)); // (n-3)/2 can only move where n >= 4 before or after
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 const int pos = __ffs(x4) - 1; x4 &= x4 - 1;
                 const int n1 = count_at(sn, pos), n0 = count_at(so, pos);
                 const int d = (n1 > 3 ? n1 - 3 : 0) - (n0 > 3 ? n0 - 3 : 0);
-                if (d) BG_PUSH(9 * (pos - 1) + 4 * sd + 3, 1, d);
+                if (d) BG_PUSH(delta_row_board(pos - 1, 4 * sd + 3), 1, d);
             }
             // bar and borne-off counters: PLAYER1 bar = pos 0, off = pos 25; PLAYER2 bar = pos 25, off = pos 0
             if (diff & 1u) {
@@ -525,10 +531,16 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
             f32x2_t a[16], a2[16];
+#if defined(BG_ABL) && (BG_ABL & 8)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { a[j] = (f32x2_t){0.25f * (float)j, 0.5f}; a2[j] = (f32x2_t){0.125f, -0.25f * (float)j}; }   // ablation: no root-term loads
+            (void)ah;
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const f32x4_t t = ah[16 * c + j]; a[2 * j] = t.lo; a[2 * j + 1] = t.hi; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const f32x4_t t = ah[16 * c + 8 + j]; a2[2 * j] = t.lo; a2[2 * j + 1] = t.hi; }
+#endif
             if (c == 1) { nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1]; }   // next tile's root row
             uint32_t ent = lst[0];
             for (uint32_t e = 0; e < maxcnt; ++e) {

@@ -623,6 +623,7 @@ struct bgamd_env {
     int n_cu = 256;
     hipStream_t side = nullptr;            // second stream: the root pass of the value net runs beside the doubles plies
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
+
     unsigned long long *tops_base = nullptr;   // [2][T_COUNT]; sv.tops points at the set of the last step
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
@@ -1081,91 +1082,115 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
     return BGAMD_OK;
 }
 
-int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision, int64_t n_steps, void *stream)
-{
-    if (!env || n_steps < 0) return BGAMD_E_INVALID;
-    HIPCHK(hipSetDevice(env->device));
-    const int slot = (flags & BGAMD_WEIGHTS_SLOT1) ? 1 : 0;
-    if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
-    if (precision != BGAMD_F32 && precision != BGAMD_BF16 && precision != BGAMD_F16X2 && precision != BGAMD_F32_DENSE)
-        return BGAMD_E_INVALID;
-    if (n_steps == 0) return BGAMD_OK;
-    hipStream_t s = (hipStream_t)stream;
-    int rc;
-    const long long n = env->v.n;
-    auto egrid = [&](long long max_items, int mode) {    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
+}  // extern "C"
+
+namespace {
+// The streams one greedy step is issued on: everything on `gen`, except the root pass of the incremental value net, which
+// goes to `root` (the env's side stream when it overlaps the doubles plies, else the same stream).
+// (A CU-partitioned variant -- move generation of one sub-batch on 64-128 masked CUs beside the value net of another on the
+// rest -- was built on this and measured 2.2-4x SLOWER: the "latency-bound" stage kernels need every CU's wave slots,
+// their time scales with 1/CUs.  profiles/r02_cu_partition_group_run.txt)
+struct StepStreams {
+    hipStream_t gen, root;
+    int n_cu;
+};
+
+// State of a run of greedy steps on one env (what bgamd_env_run_greedy kept in locals)
+struct GreedyRun {
+    bgamd_env *env;
+    int flags, slot, precision, parity = 0;
+    float epsilon;
+    bool incremental;
+    StagedView sv;
+    const float *b1, *w2, *b2;
+
+    int init(bgamd_env *e, int fl, float eps, int prec)
+    {
+        env = e; flags = fl; epsilon = eps; precision = prec;
+        slot = (fl & BGAMD_WEIGHTS_SLOT1) ? 1 : 0;
+        if (!env->has_weights[slot]) return BGAMD_E_NOWEIGHTS;
+        if (prec != BGAMD_F32 && prec != BGAMD_BF16 && prec != BGAMD_F16X2 && prec != BGAMD_F32_DENSE) return BGAMD_E_INVALID;
+        incremental = prec == BGAMD_F32;
+        b1 = env->d_w[slot] + N_HID * N_IN; w2 = b1 + N_HID; b2 = w2 + N_HID;
+        sv = env->sv;
+        sv.tops = env->tops_base;
+        parity = 0;
+        return BGAMD_OK;
+    }
+    dim3 egrid(long long max_items, int mode, int n_cu) const    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
+    {
         const int nt = expand_threads(mode);
         long long b = (max_items + nt - 1) / nt;
         // one workgroup per CU for the 1 024-thread leaf stage (82 VGPRs: that is what fits; a second round of workgroups
         // would start its latency chain from scratch, a second iteration of the same workgroup has its nodes prefetched)
-        const long long lim = (long long)env->n_cu * (nt >= 1024 ? 1 : 2048 / nt);
+        const long long lim = (long long)n_cu * (nt >= 1024 ? 1 : 2048 / nt);
         return dim3((unsigned)(b < 1 ? 1 : (b > lim ? lim : b)));
-    };
-    const bool incremental = precision == BGAMD_F32;
-    const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
+    }
     // two sets of list counters: step t uses set t & 1.  Inside a run the apply of step t and the roots of step t+1
     // share one launch (boundary_kernel); the value-net kernel of step t clears the set those roots allocate from.
-    HIPCHK(hipMemsetAsync(env->tops_base, 0, 2 * T_COUNT * 8, s));
-    int parity = 0;
-    StagedView sv = env->sv;
-    sv.tops = env->tops_base;
+    int begin(hipStream_t s)
     {
+        HIPCHK(hipMemsetAsync(env->tops_base, 0, 2 * T_COUNT * 8, s));
         KTimer t(env, s, 4);
-        hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
+        hipLaunchKernelGGL(roots_kernel, grid1(env->v.n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
+        return BGAMD_OK;
     }
-    for (int64_t step = 0; step < n_steps; ++step) {
+    int step(const StepStreams &ss, bool more)
+    {
+        const long long n = env->v.n;
+        hipStream_t s = ss.gen;
         if (incremental) {
             // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
-            // It runs on the env's second stream beside the doubles plies -- small latency-bound launches that leave
+            // It runs on a second stream beside the doubles plies -- small latency-bound launches that leave
             // most of the chip idle -- and is joined before the incremental kernel.
-            hipStream_t s2 = env->overlap ? env->side : s;
-            if (env->overlap) {
+            hipStream_t s2 = ss.root;
+            if (s2 != s) {
                 HIPCHK(hipEventRecord(env->ev_fork, s));
                 HIPCHK(hipStreamWaitEvent(s2, env->ev_fork, 0));
             }
             {
                 KTimer t(env, s2, 6);
                 if (env->root_f32_mfma)
-                    hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(env->n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
+                    hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(ss.n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
                                        (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
                                        (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
                                        (unsigned long long *)nullptr, (unsigned long long *)nullptr);
                 else {
                     long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
-                    if (blocks > env->n_cu) blocks = env->n_cu;
+                    if (blocks > ss.n_cu) blocks = ss.n_cu;
                     hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
                                        ROOT3_LDS_TOTAL, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
                                        (const uint2 *)env->d_lut, b1, sv.root_hidden);
                 }
             }
-            if (env->overlap) HIPCHK(hipEventRecord(env->ev_join, s2));
+            if (s2 != s) HIPCHK(hipEventRecord(env->ev_join, s2));
         }
         {
             KTimer t(env, s, 4);
-            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
         }
         {
             KTimer t(env, s, 5);
-            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
         }
-        const bool more = step + 1 < n_steps;
         const bool fused = more && incremental;                // the dense kernels do not clear the other counter set
         StagedView sv_next = sv;
         sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
+        hipStream_t se = s;
         if (incremental) {
-            if (env->overlap) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
-            KTimer t(env, s, 1);
+            if (ss.root != s) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
+            KTimer t(env, se, 1);
             // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
             long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
-            dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
-            hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s,
+            dblocks = dblocks < 1 ? 1 : (dblocks > ss.n_cu ? ss.n_cu : dblocks);
+            hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, se,
                                (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                                (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
                                env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS],
                                fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT, &env->v.counters[C_ERR],
                                (unsigned long long)ERRF_DELTA);
         } else {
-            rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, s);
+            const int rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, se);
             if (rc) return rc;
         }
         ExploreView xv{env->rv.tasks, env->rv.task_count, env->rv.task_off, env->rv.task_n};
@@ -1174,7 +1199,7 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
             HIPCHK(hipMemsetAsync(env->rv.top, 0, 8, s));
             hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags & ~BGAMD_ROLL, epsilon);
             long long b = (n * 4 + 255) / 256;
-            const long long lim = (long long)env->n_cu * 8;
+            const long long lim = (long long)ss.n_cu * 8;
             hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
         }
         {
@@ -1191,6 +1216,29 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
             KTimer t(env, s, 4);
             hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
         }
+        return BGAMD_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision, int64_t n_steps, void *stream)
+{
+    if (!env || n_steps < 0) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    GreedyRun run;
+    int rc = run.init(env, flags, epsilon, precision);
+    if (rc) return rc;
+    if (n_steps == 0) return BGAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const StepStreams ss{s, (run.incremental && env->overlap) ? env->side : s, env->n_cu};
+    rc = run.begin(s);
+    if (rc) return rc;
+    for (int64_t step = 0; step < n_steps; ++step) {
+        rc = run.step(ss, step + 1 < n_steps);
+        if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
     return BGAMD_OK;

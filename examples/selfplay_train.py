@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--eps", type=float, default=None, help="fixed exploration rate (overrides the linear decay)")
     ap.add_argument("--sub-round", type=int, default=0, help="replay the round in sub-rounds of this many games, weights "
                     "refreshed between them (0 = the whole round lock-step)")
+    ap.add_argument("--scale-games", type=float, default=24.0, help="every game's update is scaled by min(1, this / games per "
+                    "(sub-)round): 24 = the summed update of a reference-sized round (round_size = workers <= 24, train.py:307-312)")
+    ap.add_argument("--arena", type=int, default=1024, help="lanes of the evaluation arena (2 games per lane, sides alternated)")
+    ap.add_argument("--max-plies", type=int, default=600)
     ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
     ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
     ap.add_argument("--dist-backend", default="nccl")
@@ -66,7 +70,7 @@ def main():
         env = bg.VecGame(a.games, seed=1, lane_offset=off, lane_stride=stride)
     else:
         env = bg.VecGame(a.games, seed=1)
-    arena = bg.VecGame(1024, seed=2)
+    arena = bg.VecGame(a.arena, seed=2)
     say = print if rank == 0 else (lambda *x, **k: None)
     prec = (bg.BF16 if a.precision == "bf16" else
             bg.F16X2 if a.precision == "f16x2" or (a.precision == "auto" and a.games < 16384) else bg.F32)
@@ -86,19 +90,19 @@ def main():
         # linear decay of the exploration rate across the run (train.py:531)
         eps = a.eps if a.eps is not None else a.eps_start + (a.eps_end - a.eps_start) * (games_done / total_games)
         env.load_weights(L.theta.cpu().numpy())
-        rows, lengths, p1_won = play_round(env, max_plies=600, epsilon=eps, precision=prec)   # round r = episode r: fresh dice
+        rows, lengths, p1_won = play_round(env, max_plies=a.max_plies, epsilon=eps, precision=prec)   # round r = episode r: fresh dice
         if r < 2:                                            # every round must play NEW games
             d = env.dice().clone()
             assert first_dice is None or not torch.equal(d, first_dice), "two rounds rolled the same dice"
             first_dice = d
         sub = a.sub_round if a.sub_round > 0 else a.games
-        scale = min(1.0, 24.0 / (min(sub, a.games) * world))
+        scale = min(1.0, a.scale_games / (min(sub, a.games) * world))
         if a.host_learner:
             sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, group=group, batch_scale=scale)
         else:
             sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale, sub_round=a.sub_round)
         turns += cnt
-        if r % 20 == 19:
+        if r % 20 == 19 or r == a.rounds - 1:
             say(f"round {r + 1}: {(r + 1) * a.games * world} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
                 f"{world * turns / (time.time() - t0):.0f} turns/s", flush=True)
     w_after = L.theta.cpu().numpy()
