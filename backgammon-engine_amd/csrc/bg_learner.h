@@ -33,8 +33,8 @@ namespace bg {
 constexpr int TD_P = 25601;              // W1[128][198] | b1[128] | W2[128] | b2
 constexpr int TD_LD = 25664;             // trace row stride in floats (multiple of 64)
 constexpr int TD_OFF_B1 = 25344, TD_OFF_W2 = 25472, TD_OFF_B2 = 25600;
-// factor row of one game: x[198] | 1 | 0 | db1[128] | g·h[128] | g | pad
-constexpr int TD_F_ONE = 198, TD_F_ZERO = 199, TD_F_DB1 = 200, TD_F_GH = 328, TD_F_G = 456, TD_FLD = 464;
+// factor row of one game: the 32-byte row of s_t (8 words: the trace pass decodes x_j from it) | db1[128] | g·h[128] | g | pad
+constexpr int TD_F_ROW = 0, TD_F_DB1 = 8, TD_F_GH = 136, TD_F_G = 264, TD_FLD = 272;
 constexpr int TD_TRACE_THREADS = 256;
 constexpr int TD_SLICES = (TD_LD / 4 + TD_TRACE_THREADS - 1) / TD_TRACE_THREADS;   // 26
 #ifndef BG_TD_CHUNK
@@ -69,12 +69,51 @@ struct TdView {
     float *hid;                          // [2 * max_games][128] W1 x + b1 of (s_t, s_{t+1}) per running game, from the MFMA pass
     uint32_t *amask;                     // [max_games][TD_MASK_WORDS] features that have been non-zero in the game so far
     uint32_t *anew;                      // [max_games][TD_MASK_WORDS] ... for the first time at the current step (trace column = 0: not read)
-    unsigned long long *act_cols;        // Σ over (game, step) of active W1 trace columns since begin (traffic report)
+    unsigned int *act_cols;              // [max_games] Σ over the game's steps of its active W1 trace columns since begin (traffic report;
+                                         //   per game: a single counter would be one same-address atomic per block and step)
     int dense;                           // BGAMD_TD_DENSE=1: every column active from the first step (the dense pass)
     long long T, n_lanes, n_games;
 };
 
 __device__ __forceinline__ float td_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+// encoder feature j (model.py:111-144) of a 32-byte row held as 8 words (LDS or registers)
+__device__ __forceinline__ float td_feature_value(const uint32_t *__restrict__ row, int j)
+{
+    if (j < 192) {
+        const int pos = (j >> 3) + 1, base = 4 * ((j >> 2) & 1), level = j & 3;
+        const int cnt = (int)(((row[base] >> pos) & 1u) | (((row[base + 1] >> pos) & 1u) << 1) | (((row[base + 2] >> pos) & 1u) << 2) |
+                              (((row[base + 3] >> pos) & 1u) << 3));
+        return level < 3 ? (cnt > level ? 1.0f : 0.0f) : (cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f);
+    }
+    const int side = j & 1;                                    // 192/193 turn, 194/195 bar, 196/197 off
+    const int turn = (row[0] & TURN_BIT) ? 1 : 0;
+    if (j < 194) return turn == side ? 1.0f : 0.0f;
+    const int pos = (j < 196) == (side == 0) ? 0 : 25;         // P1 bar = 0, P2 bar = 25; P1 off = 25, P2 off = 0
+    const int base = 4 * side;
+    const int cnt = (int)(((row[base] >> pos) & 1u) | (((row[base + 1] >> pos) & 1u) << 1) | (((row[base + 2] >> pos) & 1u) << 2) |
+                          (((row[base + 3] >> pos) & 1u) << 3));
+    return j < 196 ? 0.5f * (float)cnt : (float)cnt / 15.0f;
+}
+
+// the 8 feature bits "x_j != 0" of board point pt (both sides x four levels), or the 6 bits of the tail (pt == 24)
+__device__ __forceinline__ uint32_t td_nonzero_bits(const uint32_t *__restrict__ row, int pt)
+{
+    uint32_t out = 0;
+    if (pt < 24) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pos = pt + 1, b = 4 * q;
+            const uint32_t b0 = (row[b] >> pos) & 1u, b1 = (row[b + 1] >> pos) & 1u, b2 = (row[b + 2] >> pos) & 1u, b3 = (row[b + 3] >> pos) & 1u;
+            const uint32_t ge1 = b0 | b1 | b2 | b3, ge2 = b1 | b2 | b3, ge3 = (b0 & b1) | b2 | b3, ge4 = b2 | b3;
+            out |= (ge1 | (ge2 << 1) | (ge3 << 2) | (ge4 << 3)) << (4 * q);
+        }
+        return out;
+    }
+    const uint32_t turn = (row[0] & TURN_BIT) ? 1u : 0u;
+    auto any = [&](int side, int pos) { const int b = 4 * side; return (((row[b] | row[b + 1] | row[b + 2] | row[b + 3]) >> pos) & 1u); };
+    return (turn ^ 1u) | (turn << 1) | (any(0, 0) << 2) | (any(1, 25) << 3) | (any(0, 25) << 4) | (any(1, 0) << 5);
+}
 typedef float td_f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void td_gather_kernel(TdView v)
@@ -87,6 +126,7 @@ __global__ void td_gather_kernel(TdView v)
     len = len < 0 ? 0 : (len > v.T ? (int)v.T : len);
     v.gmeta[i] = make_int4(lane, len, v.p1_won[lane] ? 1 : 0, 0);
     v.sq[i] = 0.0;
+    v.act_cols[i] = 0u;
 }
 
 // TD_GB games x {s_t, s_{t+1}} per workgroup of 128 threads (2 for small rounds: a shorter FMA chain per thread and
@@ -97,9 +137,11 @@ __global__ void td_gather_kernel(TdView v)
 template <int TD_GB, bool PRE>
 __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
 {
-    __shared__ unsigned int s_cols;
     constexpr int NR = 2 * TD_GB;                         // rows: [s][game]
-    __shared__ __attribute__((aligned(16))) float xs[N_IN][NR];
+    __shared__ unsigned int s_colsg[TD_GB];
+    __shared__ __attribute__((aligned(16))) float xs[PRE ? 1 : N_IN][NR];
+    __shared__ uint32_t srow[TD_GB][8];                   // the 32-byte row of s_t of every game of the block
+    __shared__ uint32_t smask[TD_GB][TD_MASK_WORDS];
     __shared__ float hs[NR][N_HID + 1];
     __shared__ float outs[NR];
     __shared__ float gs[TD_GB];
@@ -113,72 +155,57 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         for (int j = 0; j < N_IN; ++j) w[j] = v.w1t[j * N_HID + tid];
     }
 
-    // ---- decode: thread = (row r, chunk c): board points c, c + CH, ... ----
+    // ---- the rows: thread = (row r, chunk c) ----
     constexpr int CH = 128 / NR;                          // chunks (threads per row)
+    if (tid < TD_GB * TD_MASK_WORDS) (&smask[0][0])[tid] = 0;
     {
         const int r = tid & (NR - 1), c = tid / NR;
         const int s = r / TD_GB, g = r % TD_GB;
         const long long i = i0 + g;
         bool live = i < n_active;
         int lane = 0;
-        if (live) {
+        if (live && (!PRE || (s == 0 && c == 0))) {
             const int4 gm = v.gmeta[i];
             lane = gm.x;
             live = (t + s) < gm.y && (t + s) < v.T;       // s_{t+1} does not exist on the terminal step
-        }
+        } else if (PRE) live = false;                     // the matrix-pipe pass has decoded the rows: only s_t is needed here, once
         uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
             const uint4 *src = v.rows + ((t + s) * v.n_lanes + lane) * 2;
             const uint4 u0 = src[0], u1 = src[1];
             p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
         }
-        const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
+        if (s == 0 && c == 0) {
 #pragma unroll
-        for (int k = 0; k < (24 + CH - 1) / CH; ++k) {
-            const int pt = c + CH * k;
-            if (pt >= 24) break;
+            for (int k = 0; k < 8; ++k) srow[g][k] = p[k];
+        }
+        if (!PRE) {                                       // the VALU path needs the 198 floats of both states
+            const Side sd[2] = {{{p[0], p[1], p[2], p[3]}}, {{p[4], p[5], p[6], p[7]}}};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int cn = count_at(sd[q], pt + 1);
-                xs[8 * pt + 4 * q + 0][r] = cn >= 1 ? 1.0f : 0.0f;
-                xs[8 * pt + 4 * q + 1][r] = cn >= 2 ? 1.0f : 0.0f;
-                xs[8 * pt + 4 * q + 2][r] = cn >= 3 ? 1.0f : 0.0f;
-                xs[8 * pt + 4 * q + 3][r] = cn >= 4 ? 0.5f * (float)(cn - 3) : 0.0f;
+            for (int k = 0; k < (24 + CH - 1) / CH; ++k) {
+                const int pt = c + CH * k;
+                if (pt >= 24) break;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cn = count_at(sd[q], pt + 1);
+                    xs[8 * pt + 4 * q + 0][r] = cn >= 1 ? 1.0f : 0.0f;
+                    xs[8 * pt + 4 * q + 1][r] = cn >= 2 ? 1.0f : 0.0f;
+                    xs[8 * pt + 4 * q + 2][r] = cn >= 3 ? 1.0f : 0.0f;
+                    xs[8 * pt + 4 * q + 3][r] = cn >= 4 ? 0.5f * (float)(cn - 3) : 0.0f;
+                }
+            }
+            if (c == 0) {
+                const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+                xs[192][r] = live ? (turn == 0 ? 1.0f : 0.0f) : 0.0f;
+                xs[193][r] = live ? (turn == 0 ? 0.0f : 1.0f) : 0.0f;
+                xs[194][r] = 0.5f * (float)count_at(sd[0], 0);
+                xs[195][r] = 0.5f * (float)count_at(sd[1], 25);
+                xs[196][r] = (float)count_at(sd[0], 25) / 15.0f;
+                xs[197][r] = (float)count_at(sd[1], 0) / 15.0f;
             }
         }
-        if (c == 0) {
-            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
-            xs[192][r] = live ? (turn == 0 ? 1.0f : 0.0f) : 0.0f;
-            xs[193][r] = live ? (turn == 0 ? 0.0f : 1.0f) : 0.0f;
-            xs[194][r] = 0.5f * (float)count_at(sd[0], 0);
-            xs[195][r] = 0.5f * (float)count_at(sd[1], 25);
-            xs[196][r] = (float)count_at(sd[0], 25) / 15.0f;
-            xs[197][r] = (float)count_at(sd[1], 0) / 15.0f;
-        }
     }
-    if (tid == 0) s_cols = 0;
-    __syncthreads();
-    // ---- ever-active feature masks of the games (thread = (game, word)): the trace pass touches only these columns ----
-    if (tid < TD_GB * TD_MASK_WORDS) {
-        const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
-        const long long i = i0 + g;
-        if (i < n_active) {
-            uint32_t now = 0;
-#pragma unroll 8
-            for (int b = 0; b < 32; ++b) {
-                const int j = 32 * wd + b;
-                if (j < N_IN && xs[j][g] != 0.0f) now |= 1u << b;          // row g = state s_t of game g
-            }
-            const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);     // 198 = 6 * 32 + 6
-            if (v.dense) now = valid;
-            const uint32_t old = t == 0 ? 0u : v.amask[i * TD_MASK_WORDS + wd];
-            v.amask[i * TD_MASK_WORDS + wd] = old | now;
-            v.anew[i * TD_MASK_WORDS + wd] = now & ~old;
-            atomicAdd(&s_cols, (unsigned int)__popc(old | now));
-        }
-    }
-
-    // ---- hidden layer: thread n owns unit n for all 16 rows ----
+    // the hidden pre-activations of the matrix-pipe pass and this thread's weights: requested before the first barrier
     const int n = tid;
     float acc[NR];
     if (PRE) {
@@ -187,7 +214,36 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
             const long long i = i0 + (r % TD_GB);
             acc[r] = i < n_active ? v.hid[(2 * i + r / TD_GB) * N_HID + n] : 0.0f;
         }
-    } else {
+    }
+    const float w2 = v.theta[TD_OFF_W2 + n];
+    if (tid < TD_GB) s_colsg[tid] = 0;
+    __syncthreads();
+    // ---- ever-active feature masks of the games: thread = (game, board point | tail) ORs its 8 (6) "x_j != 0" bits into the
+    //      game's mask words; the trace pass touches only these columns ----
+    if (tid < TD_GB * 25) {
+        const int g = tid / 25, pt = tid % 25;
+        if (i0 + g < n_active) {
+            const uint32_t bits = td_nonzero_bits(srow[g], pt);
+            if (bits) atomicOr(&smask[g][pt >> 2], bits << (8 * (pt & 3)));      // word = 4 points (8 features each); tail = word 6
+        }
+    }
+    __syncthreads();
+    if (tid < TD_GB * TD_MASK_WORDS) {
+        const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
+        const long long i = i0 + g;
+        if (i < n_active) {
+            uint32_t now = smask[g][wd];
+            const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);     // 198 = 6 * 32 + 6
+            if (v.dense) now = valid;
+            const uint32_t old = t == 0 ? 0u : v.amask[i * TD_MASK_WORDS + wd];
+            v.amask[i * TD_MASK_WORDS + wd] = old | now;
+            v.anew[i * TD_MASK_WORDS + wd] = now & ~old;
+            atomicAdd(&s_colsg[g], (unsigned int)__popc(old | now));
+        }
+    }
+
+    // ---- hidden layer: thread n owns unit n for all 16 rows ----
+    if (!PRE) {
         const float b = v.theta[TD_OFF_B1 + n];
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[r] = b;
@@ -204,7 +260,6 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
             }
         }
     }
-    const float w2 = v.theta[TD_OFF_W2 + n];
     float h[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -248,11 +303,63 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const float g = gs[gq], hh = h[gq];
         f[TD_F_DB1 + n] = (g * w2) * (1.0f - hh) * hh;
         f[TD_F_GH + n] = g * hh;
-        f[n] = xs[n][gq];
-        if (n + 128 < N_IN) f[n + 128] = xs[n + 128][gq];
-        if (n == 0) { f[TD_F_ONE] = 1.0f; f[TD_F_ZERO] = 0.0f; f[TD_F_G] = g; }
+        if (n < 8) f[TD_F_ROW + n] = __uint_as_float(srow[gq][n]);
+        if (n == 8) f[TD_F_G] = g;
     }
-    if (tid == 0 && s_cols) atomicAdd(v.act_cols, (unsigned long long)s_cols);     // (the barriers above ordered the LDS adds)
+    if (tid < TD_GB && i0 + tid < n_active) v.act_cols[i0 + tid] += s_colsg[tid];  // (the barriers above ordered the LDS adds)
+}
+
+// Epilogue of the matrix-pipe forward pass, ONE WAVE PER GAME (4 games per 256-thread block, no LDS, no block barrier): lane l
+// owns hidden units l and l + 64 of s_t and s_{t+1}; h = σ(·), the dot with W2 by a wave reduction, v, δ, g, coef, the
+// factor row (32-byte row of s_t | db1 | g·h | g) and the game's ever-active feature mask.  The chain of dependent memory
+// accesses is gmeta -> row; everything else is requested up front.  (The thread-per-unit kernel above, with its four block
+// barriers and six dependent round trips per block, took 126 us per step at 65 536 games for 140 MB of traffic.)
+__global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long long t, long long n_active, double alpha)
+{
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_active) return;                                 // whole waves leave: no barrier below
+    const int4 gm = v.gmeta[i];
+    const float *hp = v.hid + 2 * i * N_HID;
+    const float a0 = hp[lane], a1 = hp[lane + 64], c0 = hp[N_HID + lane], c1 = hp[N_HID + lane + 64];     // s_t | s_{t+1}
+    const float w20 = v.theta[TD_OFF_W2 + lane], w21 = v.theta[TD_OFF_W2 + lane + 64], b2 = v.theta[TD_OFF_B2];
+    uint32_t old = 0;
+    if (t != 0 && lane < TD_MASK_WORDS) old = v.amask[i * TD_MASK_WORDS + lane];
+    const uint4 *src = v.rows + (t * v.n_lanes + gm.x) * 2;    // s_t exists for every running game
+    const uint4 u0 = src[0], u1 = src[1];
+    const uint32_t row[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    const float h0 = td_sigmoid(a0), h1 = td_sigmoid(a1), k0 = td_sigmoid(c0), k1 = td_sigmoid(c1);
+    float sv = w20 * h0 + w21 * h1, sn = w20 * k0 + w21 * k1;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { sv += __shfl_xor(sv, m, 64); sn += __shfl_xor(sn, m, 64); }
+    const float val = td_sigmoid(sv + b2), vnext = td_sigmoid(sn + b2);
+    const float z = gm.z ? 1.0f : 0.0f;
+    const float delta = (t + 1 >= gm.y) ? z - val : vnext - val;
+    const float g = val * (1.0f - val);
+    float *f = v.fac + i * TD_FLD;
+    f[TD_F_DB1 + lane] = (g * w20) * (1.0f - h0) * h0;
+    f[TD_F_DB1 + lane + 64] = (g * w21) * (1.0f - h1) * h1;
+    f[TD_F_GH + lane] = g * h0;
+    f[TD_F_GH + lane + 64] = g * h1;
+    if (lane < 8) f[TD_F_ROW + lane] = __uint_as_float(row[lane & 7]);
+    if (lane == 8) f[TD_F_G] = g;
+    if (lane == 9) { v.coef[i] = (float)(alpha * (double)delta); v.sq[i] += (double)delta * (double)delta; }
+    // ever-active feature mask: lane pt < 25 forms the 8 (6) "x_j != 0" bits of board point pt (the tail), a quad of lanes
+    // is one 32-bit word
+    uint32_t bits = lane < 25 ? td_nonzero_bits(row, lane) << (8 * (lane & 3)) : 0u;
+    bits |= __shfl_xor(bits, 1, 64);
+    bits |= __shfl_xor(bits, 2, 64);
+    uint32_t now = __shfl(bits, 4 * (lane & 7), 64);           // lane w < 7 takes word w from lane 4 w
+    if (lane < TD_MASK_WORDS) {
+        const uint32_t valid = lane < 6 ? 0xFFFFFFFFu : (lane == 6 ? 0x3Fu : 0u);
+        now = v.dense ? valid : (now & valid);
+        v.amask[i * TD_MASK_WORDS + lane] = old | now;
+        v.anew[i * TD_MASK_WORDS + lane] = now & ~old;
+    }
+    unsigned int cols = lane < TD_MASK_WORDS ? (unsigned int)__popc(old | now) : 0u;
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) cols += __shfl_xor(cols, m, 64);
+    if (lane == 0) v.act_cols[i] += cols;
 }
 
 // grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace (internal order); `ng` games per group.
@@ -262,13 +369,11 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
 template <bool FIRST>
 __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, long long n_active, int ng, float lambda)
 {
-    // what a slice needs of a game's factor row: the 8 features of its 1 024 positions (x[jb .. jb+7]; for the last slices
-    // that window is x[192..197] | 1 | 0), and db1 | g·h | g
-    constexpr int L_X = 0, L_DB1 = 8, L_GH = L_DB1 + N_HID, L_G = L_GH + N_HID, L_LD = 268;
+    // a game's factor row: its 32-byte row (x_j is decoded from it) | db1 | g·h | g
+    constexpr int L_DB1 = TD_F_DB1, L_GH = TD_F_GH, L_G = TD_F_G, L_LD = TD_FLD;
     __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][L_LD];
     __shared__ float cs[TD_CHUNK];
     __shared__ uint32_t ms[TD_CHUNK][TD_MASK_WORDS], ns[TD_CHUNK][TD_MASK_WORDS];
-    const int jb = blockIdx.x * 8 < 192 ? blockIdx.x * 8 : 192;
     const int tid = threadIdx.x;
     const int p0 = (blockIdx.x * TD_TRACE_THREADS + tid) * 4;
     const bool in_row = p0 < TD_LD;
@@ -277,16 +382,18 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
     const int mword = jw >> 5;
     const uint32_t mbit = 1u << (jw & 31);
     const long long g0 = (long long)blockIdx.y * ng;
-    int ia[4], ib[4];
+    // gradient of position p = fs[ia] * xj, xj = the thread's feature x_j (W1 block), 1 (b1 | W2 | b2) or 0 (padding)
+    int ia[4];
+    float xfix[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = p0 + k;
-        constexpr int ONE = L_X + (TD_F_ONE - 192), ZERO = L_X + (TD_F_ZERO - 192);     // in the window of the last slices
-        if (p < TD_OFF_B1) { ia[k] = L_DB1 + (p & (N_HID - 1)); ib[k] = L_X + (p >> 7) - jb; }
-        else if (p < TD_OFF_W2) { ia[k] = L_DB1 + (p - TD_OFF_B1); ib[k] = ONE; }
-        else if (p < TD_OFF_B2) { ia[k] = L_GH + (p - TD_OFF_W2); ib[k] = ONE; }
-        else if (p == TD_OFF_B2) { ia[k] = L_G; ib[k] = ONE; }
-        else { ia[k] = ZERO; ib[k] = ZERO; }
+        xfix[k] = 1.0f;
+        if (p < TD_OFF_B1) ia[k] = L_DB1 + (p & (N_HID - 1));
+        else if (p < TD_OFF_W2) ia[k] = L_DB1 + (p - TD_OFF_B1);
+        else if (p < TD_OFF_B2) ia[k] = L_GH + (p - TD_OFF_W2);
+        else if (p == TD_OFF_B2) ia[k] = L_G;
+        else { ia[k] = L_G; xfix[k] = 0.0f; }
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < ng; c += TD_CHUNK) {
@@ -297,13 +404,9 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
         const int m = left < TD_CHUNK ? (int)left : TD_CHUNK;
         __syncthreads();
         {
-            constexpr int ROW4 = L_LD / 4;                       // 67 float4 per game: 2 of the x window, 65 of db1 | g·h | g
-            for (int q = tid; q < m * ROW4; q += TD_TRACE_THREADS) {
-                const int gq = q / ROW4, c4 = q - gq * ROW4;
-                const float *f = v.fac + (gb + gq) * TD_FLD;
-                reinterpret_cast<float4 *>(&fs[gq][0])[c4] =
-                    *reinterpret_cast<const float4 *>(c4 < 2 ? f + jb + 4 * c4 : f + TD_F_DB1 + 4 * (c4 - 2));
-            }
+            const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
+            float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
+            for (int q = tid; q < m * (TD_FLD / 4); q += TD_TRACE_THREADS) dst[q] = src[q];
             if (tid < m) cs[tid] = v.coef[gb + tid];
             if (tid < m * TD_MASK_WORDS) {
                 (&ms[0][0])[tid] = v.amask[gb * TD_MASK_WORDS + tid];
@@ -333,14 +436,18 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
                 ev[q] = __builtin_nontemporal_load(ep);
             }
         }
+
 #pragma unroll
         for (int q = 0; q < TD_CHUNK; ++q) {
             if ((act >> q) & 1u) {
                 td_f32x4 x = ev[q];
-                x.x = fmaf(lambda, x.x, fs[q][ia[0]] * fs[q][ib[0]]);
-                x.y = fmaf(lambda, x.y, fs[q][ia[1]] * fs[q][ib[1]]);
-                x.z = fmaf(lambda, x.z, fs[q][ia[2]] * fs[q][ib[2]]);
-                x.w = fmaf(lambda, x.w, fs[q][ia[3]] * fs[q][ib[3]]);
+                // (decoded per thread: one decode per (slice, game) shared through LDS costs a third barrier per chunk and
+                //  was slower, 98.1 vs 96.2 ms per 65 536-game replay)
+                const float xj = is_w1 ? td_feature_value(reinterpret_cast<const uint32_t *>(&fs[q][TD_F_ROW]), jw) : 1.0f;
+                x.x = fmaf(lambda, x.x, fs[q][ia[0]] * (is_w1 ? xj : xfix[0]));
+                x.y = fmaf(lambda, x.y, fs[q][ia[1]] * (is_w1 ? xj : xfix[1]));
+                x.z = fmaf(lambda, x.z, fs[q][ia[2]] * (is_w1 ? xj : xfix[2]));
+                x.w = fmaf(lambda, x.w, fs[q][ia[3]] * (is_w1 ? xj : xfix[3]));
                 td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
                 __builtin_nontemporal_store(x, ep);
                 const float cf = cs[q];

@@ -1522,7 +1522,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.partial, (size_t)TD_MAX_GROUPS * TD_LD * 4);
     TDALLOC(v.amask, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.anew, (size_t)max_games * TD_MASK_WORDS * 4);
-    TDALLOC(v.act_cols, 8);
+    TDALLOC(v.act_cols, (size_t)max_games * 4);
     TDALLOC(v.wl3, 3 * EVAL16_W_BYTES);
     TDALLOC(v.lut, EVAL16_LUT_BYTES);
     TDALLOC(v.hid, (size_t)max_games * 2 * N_HID * 4);
@@ -1539,7 +1539,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
         td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 3072;
     }
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
-    HIPCHK(hipMemset(v.act_cols, 0, 8));
+    HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
     HIPCHK(hipMemset(v.theta, 0, TD_LD * 4));
     HIPCHK(hipMemset(v.sq, 0, (size_t)max_games * 8));
     *out = td;
@@ -1595,7 +1595,6 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
         hipLaunchKernelGGL(td_gather_kernel, grid1(n_games, 256), dim3(256), 0, (hipStream_t)stream, v);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemsetAsync(v.act_cols, 0, 8, (hipStream_t)stream));
     td->updates = 0;
     td->begun = true;
     return BGAMD_OK;
@@ -1621,7 +1620,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         hipLaunchKernelGGL(traj_hidden_bf16x3_kernel, dim3((unsigned)blocks), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s, v.rows,
                            (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
                            (const float *)(v.theta + TD_OFF_B1), v.hid);
-        hipLaunchKernelGGL((td_forward_kernel<4, true>), grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
+        hipLaunchKernelGGL(td_epilogue_wave_kernel, grid1(n_active, 4), dim3(256), 0, s, v, (long long)t, (long long)n_active, alpha);
     } else if (n_active <= 8192)
         hipLaunchKernelGGL((td_forward_kernel<2, false>), grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     else
@@ -1700,9 +1699,11 @@ int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns)
     if (!td || !h_columns) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long c = 0;
-    HIPCHK(hipMemcpy(&c, td->v.act_cols, 8, hipMemcpyDeviceToHost));
-    *h_columns = (uint64_t)c;
+    std::vector<unsigned int> c((size_t)td->v.n_games);
+    if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.act_cols, c.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (unsigned int x : c) tot += x;
+    *h_columns = tot;
     return BGAMD_OK;
 }
 
