@@ -407,7 +407,7 @@ class Game:
         _next_scalar_id += 1
         self._players = [None, None]
         self._snap = None
-        self._v.set_states(None, [int(player) % 2])          # Game::Game(int): turn = parity (game.cpp:44-53)
+        self._put(None, int(player) % 2)                     # Game::Game(int): turn = parity (game.cpp:44-53)
 
     def __del__(self):
         v = getattr(self, "_v", None)
@@ -423,9 +423,17 @@ class Game:
         self._snap = None
 
     def _s(self):
+        """state28 | turn | die1 | die2 | flags: ONE call of the host-argument scalar surface (bgamd_game_snapshot)."""
         if self._snap is None:
-            self._snap = self._v.snapshot()[0].cpu().tolist()
+            buf = (C.c_int32 * 32)()
+            _capi.check(self._v._lib.bgamd_game_snapshot(self._v._h, buf), "snapshot")
+            self._snap = list(buf)
         return self._snap
+
+    def _put(self, state28=None, turn=-1):
+        arr = (C.c_int32 * 28)(*[int(v) for v in state28]) if state28 is not None else None
+        _capi.check(self._v._lib.bgamd_game_set_state(self._v._h, arr, int(turn)), "set_state")
+        self._dirty()
 
     # players ------------------------------------------------------------------------------
     def setPlayers(self, p1: Player, p2: Player):
@@ -440,8 +448,7 @@ class Game:
         return self._s()[28]
 
     def setTurn(self, turn):
-        self._v.set_states(None, [int(turn) & 1])
-        self._dirty()
+        self._put(None, int(turn) & 1)
 
     def _state(self):
         return list(self._s()[:28])
@@ -463,29 +470,25 @@ class Game:
         if len(board) != 24:
             raise ValueError("gameboard must have 24 entries")
         s = self._state()
-        self._v.set_states([board + s[24:]], None)
-        self._dirty()
+        self._put(board + s[24:])
 
     def setBorneOffPieces(self, player, num):
         s = self._state()
         s[26 + (0 if int(player) == 0 else 1)] = int(num)
-        self._v.set_states([s], None)
-        self._dirty()
+        self._put(s)
 
     def _set_jailed(self, player, num):
         """Not in the reference binding (bar counts are only reachable by hits); used by tests/clone."""
         s = self._state()
         s[24 + (0 if int(player) == 0 else 1)] = int(num)
-        self._v.set_states([s], None)
-        self._dirty()
+        self._put(s)
 
     def reset(self):
         self.populateBoard()                                   # binding maps reset -> populateBoard only
 
     def populateBoard(self):
         s = self._state()
-        self._v.set_states([[2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2] + s[24:]], None)
-        self._dirty()
+        self._put([2, 0, 0, 0, 0, -5, 0, -3, 0, 0, 0, 5, -5, 0, 0, 0, 3, 0, 5, 0, 0, 0, 0, -2] + s[24:])
 
     def printGameBoard(self):
         s = self._state()
@@ -493,13 +496,14 @@ class Game:
 
     # dice -------------------------------------------------------------------------------------
     def setDice(self, d1, d2):
-        self._v.set_dice([[int(d1), int(d2)]])
+        _capi.check(self._v._lib.bgamd_game_set_dice(self._v._h, int(d1), int(d2)), "setDice")
         self._dirty()
 
     def roll_dice(self):
-        self._v.roll(advance_ply=True)
+        d = (C.c_int32 * 2)()
+        _capi.check(self._v._lib.bgamd_game_roll(self._v._h, d), "roll_dice")
         self._dirty()
-        return self.get_last_dice()
+        return [int(d[0]), int(d[1])]
 
     def get_last_dice(self):
         d = self._s()[29:31]
@@ -507,26 +511,34 @@ class Game:
 
     # rules --------------------------------------------------------------------------------------
     def legalMoves(self, player, die):
-        n, pairs = self._v.legal_moves([int(player)], [int(die)])
-        k = int(n[0])
-        return [(int(a), int(b)) for a, b in pairs[0, :k].cpu().tolist()]
+        pairs = (C.c_int8 * 52)()
+        k = _capi.check(self._v._lib.bgamd_game_legal_moves(self._v._h, int(player), int(die), pairs), "legalMoves")
+        return [(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(k)]
 
-    def _enumerate(self, player, d1, d2):
-        _, cnts, st, sq, ln = self._v.enumerate([int(player)], [[int(d1), int(d2)]])
-        k = int(cnts[0])
-        sq, ln = sq[:k].cpu().numpy(), ln[:k].cpu().numpy()
-        seqs = [[(int(sq[i, j, 0]), int(sq[i, j, 1])) for j in range(ln[i])] for i in range(k)]
-        return seqs, st[:k]
+    def _enumerate(self, player, d1, d2, want_states=True):
+        """One call of bgamd_game_enumerate when the list fits the first guess, a second one otherwise."""
+        cap = 2048
+        for _ in range(2):
+            st = np.empty((cap, 28), dtype=np.int32) if want_states else None
+            sq, ln = np.empty((cap, 4, 2), dtype=np.int8), np.empty((cap,), dtype=np.int32)
+            k = _capi.check(self._v._lib.bgamd_game_enumerate(self._v._h, int(player), int(d1), int(d2),
+                                                             st.ctypes.data_as(C.c_void_p) if want_states else None,
+                                                             sq.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), cap), "enumerate")
+            if k <= cap:
+                break
+            cap = k
+        sql, lnl = sq[:k].tolist(), ln[:k].tolist()
+        seqs = [[(sql[i][j][0], sql[i][j][1]) for j in range(lnl[i])] for i in range(k)]
+        return seqs, (st[:k].copy() if want_states else None)
 
     def legalTurnSequences(self, player, die1, die2):
-        return self._enumerate(player, die1, die2)[0]
+        return self._enumerate(player, die1, die2, want_states=False)[0]
 
     def evaluateTurnSequences(self, player, die1, die2):
-        seqs, st = self._enumerate(player, die1, die2)
-        return seqs, st.cpu().numpy().astype(np.int32).reshape(-1, 28)
+        return self._enumerate(player, die1, die2)
 
     def tryMove(self, player: Player, dice, origin, dest):
-        err = int(self._v.try_move([player.getNum()], [int(dice)], [int(origin)], [int(dest)])[0])
+        err = _capi.check(self._v._lib.bgamd_game_try_move(self._v._h, player.getNum(), int(dice), int(origin), int(dest)), "tryMove")
         if err == 0:
             self._dirty()
         return err == 0, ERR_MESSAGES[err]
@@ -539,6 +551,5 @@ class Game:
         g = Game(0)
         g._players = list(self._players)
         s = self._s()
-        g._v.set_states([s[:28]], [s[28]])                     # last_dice stays [1,1] (game.cpp:68-77)
-        g._dirty()
+        g._put(s[:28], s[28])                                  # last_dice stays [1,1] (game.cpp:68-77)
         return g

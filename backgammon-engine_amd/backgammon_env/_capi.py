@@ -35,6 +35,13 @@ SYMBOLS = [
     ("bgamd_env_get_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_flags", C.c_int, [_P, _P, _P]),
     ("bgamd_env_snapshot", C.c_int, [_P, _P, _P]),
+    ("bgamd_game_snapshot", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("bgamd_game_set_state", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int]),
+    ("bgamd_game_set_dice", C.c_int, [_P, C.c_int, C.c_int]),
+    ("bgamd_game_roll", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("bgamd_game_legal_moves", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int8)]),
+    ("bgamd_game_try_move", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("bgamd_game_enumerate", C.c_int64, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int64]),
     ("bgamd_env_set_dice", C.c_int, [_P, _P, _P]),
     ("bgamd_env_get_dice", C.c_int, [_P, _P, _P]),
     ("bgamd_env_roll", C.c_int, [_P, C.c_int, _P]),

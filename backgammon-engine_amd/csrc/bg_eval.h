@@ -742,7 +742,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_bf16_kernel(
 // (root positions); output = -log2(e) (W1 x + b1), what eval_rows_delta_kernel starts from.
 // The three weight planes (160 KB) do not fit LDS together: K is staged in two phases (7 + 6 K-steps).
 constexpr int ROOT3_THREADS = 512;
-constexpr int ROOT3_PHASE_STEPS = 7;
+#ifndef BG_ROOT3_PHASE_STEPS
+#define BG_ROOT3_PHASE_STEPS 7
+#endif
+constexpr int ROOT3_PHASE_STEPS = BG_ROOT3_PHASE_STEPS;     // K-steps staged in LDS at a time (13 = all three planes at once: 159 872 B)
+constexpr int ROOT3_PHASES = (K16_STEPS + ROOT3_PHASE_STEPS - 1) / ROOT3_PHASE_STEPS;
 constexpr int ROOT3_PART_U4 = K16_STEPS * 4 * 64;                                  // uint4 per weight plane
 constexpr int ROOT3_LDS_TOTAL = 3 * ROOT3_PHASE_STEPS * 4 * 64 * 16 + EVAL16_LUT_BYTES;   // 86 144
 
@@ -820,9 +824,9 @@ __device__ __forceinline__ void root3_body(const Fetch fetch, long long n_rows, 
         const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
         floatx16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
 #pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
+        for (int phase = 0; phase < ROOT3_PHASES; ++phase) {
             const int s0 = phase * ROOT3_PHASE_STEPS;
-            const int ns = phase == 0 ? ROOT3_PHASE_STEPS : K16_STEPS - ROOT3_PHASE_STEPS;
+            const int ns = K16_STEPS - s0 < ROOT3_PHASE_STEPS ? K16_STEPS - s0 : ROOT3_PHASE_STEPS;
             __syncthreads();                                 // the previous phase's readers are done
             for (int i = threadIdx.x; i < 3 * ns * 4 * 64; i += ROOT3_THREADS) {
                 const int part = i / (ns * 4 * 64), o = i - part * (ns * 4 * 64);

@@ -625,6 +625,9 @@ struct bgamd_env {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
 
     unsigned long long *tops_base = nullptr;   // [2][T_COUNT]; sv.tops points at the set of the last step
+    int32_t *d_scalar = nullptr;           // device staging of the scalar (host-argument) surface: args at [0..63], results behind
+    void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
+    size_t tmp_bytes = 0;
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     // kernel timing
@@ -839,6 +842,8 @@ int bgamd_env_destroy(bgamd_env *env)
                     v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (env->d_scalar) hipFree(env->d_scalar);
+    if (env->d_tmp) hipFree(env->d_tmp);
     for (hipEvent_t e : env->ev) hipEventDestroy(e);
     if (env->ev_fork) hipEventDestroy(env->ev_fork);
     if (env->ev_join) hipEventDestroy(env->ev_join);
@@ -910,6 +915,121 @@ int bgamd_env_snapshot(bgamd_env *env, int32_t *d_out, void *stream)
     hipLaunchKernelGGL(snapshot_kernel, grid1(env->v.n, 128), dim3(128), 0, (hipStream_t)stream, env->v, d_out);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
+}
+
+// ---- scalar surface with host arguments (one-lane envs) ----
+static int launch_emit(bgamd_env *env, int flags, int with_seq, const int32_t *ov_player, const int32_t *ov_dice, hipStream_t s);
+static int check_err_flags(bgamd_env *env, unsigned long long f);
+static int scalar_guard(bgamd_env *env)
+{
+    if (!env || env->v.n != 1) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    if (!env->d_scalar) HIPCHK(hipMalloc(&env->d_scalar, 1024 * 4));
+    return BGAMD_OK;
+}
+
+int bgamd_game_snapshot(bgamd_env *env, int32_t h_out[32])
+{
+    int rc = scalar_guard(env);
+    if (rc || !h_out) return rc ? rc : BGAMD_E_INVALID;
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, nullptr, env->v, env->d_scalar + 64);
+    HIPCHK(hipMemcpy(h_out, env->d_scalar + 64, 32 * 4, hipMemcpyDeviceToHost));
+    return BGAMD_OK;
+}
+
+int bgamd_game_set_state(bgamd_env *env, const int32_t *h_state28, int turn)
+{
+    int rc = scalar_guard(env);
+    if (rc || (!h_state28 && turn < 0)) return rc ? rc : BGAMD_E_INVALID;
+    int32_t h[29];
+    if (h_state28) memcpy(h, h_state28, 28 * 4);
+    h[28] = turn;
+    HIPCHK(hipMemcpy(env->d_scalar, h, 29 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(set_states_kernel, dim3(1), dim3(64), 0, nullptr, env->v, h_state28 ? (const int32_t *)env->d_scalar : nullptr,
+                       turn >= 0 ? (const int32_t *)(env->d_scalar + 28) : nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    return BGAMD_OK;
+}
+
+int bgamd_game_set_dice(bgamd_env *env, int d1, int d2)
+{
+    int rc = scalar_guard(env);
+    if (rc) return rc;
+    const int32_t h[2] = {d1, d2};
+    HIPCHK(hipMemcpy(env->d_scalar, h, 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dice_kernel, dim3(1), dim3(64), 0, nullptr, env->v, (const int32_t *)env->d_scalar, (int32_t *)nullptr, 0);
+    HIPCHK(hipDeviceSynchronize());
+    return BGAMD_OK;
+}
+
+int bgamd_game_roll(bgamd_env *env, int32_t h_dice[2])
+{
+    int rc = scalar_guard(env);
+    if (rc || !h_dice) return rc ? rc : BGAMD_E_INVALID;
+    hipLaunchKernelGGL(dice_kernel, dim3(1), dim3(64), 0, nullptr, env->v, (const int32_t *)nullptr, env->d_scalar + 64, 2);
+    HIPCHK(hipMemcpy(h_dice, env->d_scalar + 64, 8, hipMemcpyDeviceToHost));
+    return BGAMD_OK;
+}
+
+int bgamd_game_legal_moves(bgamd_env *env, int player, int die, int8_t *h_pairs)
+{
+    int rc = scalar_guard(env);
+    if (rc || !h_pairs) return rc ? rc : BGAMD_E_INVALID;
+    const int32_t h[2] = {player, die};
+    HIPCHK(hipMemcpy(env->d_scalar, h, 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(legal_moves_kernel, dim3(1), dim3(64), 0, nullptr, env->v, (const int32_t *)env->d_scalar, (const int32_t *)(env->d_scalar + 1),
+                       env->d_scalar + 64, (int8_t *)(env->d_scalar + 80));
+    int32_t out[1 + 13];
+    HIPCHK(hipMemcpy(out, env->d_scalar + 64, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_pairs, env->d_scalar + 80, 52, hipMemcpyDeviceToHost));
+    return out[0];
+}
+
+int bgamd_game_try_move(bgamd_env *env, int player, int dice, int origin, int dest)
+{
+    int rc = scalar_guard(env);
+    if (rc) return rc;
+    const int32_t h[4] = {player, dice, origin, dest};
+    HIPCHK(hipMemcpy(env->d_scalar, h, 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(try_move_kernel, dim3(1), dim3(64), 0, nullptr, env->v, (const int32_t *)env->d_scalar, (const int32_t *)(env->d_scalar + 1),
+                       (const int32_t *)(env->d_scalar + 2), (const int32_t *)(env->d_scalar + 3), env->d_scalar + 64);
+    int32_t code = 0;
+    HIPCHK(hipMemcpy(&code, env->d_scalar + 64, 4, hipMemcpyDeviceToHost));
+    return code;
+}
+
+int64_t bgamd_game_enumerate(bgamd_env *env, int player, int d1, int d2, int32_t *h_states28, int8_t *h_seq, int32_t *h_len, int64_t cap)
+{
+    int rc = scalar_guard(env);
+    if (rc || cap < 0) return rc ? rc : BGAMD_E_INVALID;
+    const int32_t h[3] = {player, d1, d2};
+    HIPCHK(hipMemcpy(env->d_scalar, h, 12, hipMemcpyHostToDevice));
+    rc = launch_emit(env, 0, 1, (const int32_t *)env->d_scalar, (const int32_t *)(env->d_scalar + 1), nullptr);
+    if (rc) return rc;
+    unsigned long long hc[C_COUNT];
+    HIPCHK(hipMemcpy(hc, env->v.counters, sizeof hc, hipMemcpyDeviceToHost));
+    rc = check_err_flags(env, hc[C_ERR]);
+    if (rc) return rc;
+    const long long C = (long long)hc[C_ARENA_TOP];
+    const long long m = C < cap ? C : cap;
+    if (m > 0 && (h_states28 || h_seq || h_len)) {
+        const size_t need = (size_t)m * (28 * 4 + 8 + 4);
+        if (need > env->tmp_bytes) {
+            if (env->d_tmp) hipFree(env->d_tmp);
+            env->d_tmp = nullptr; env->tmp_bytes = 0;
+            HIPCHK(hipMalloc(&env->d_tmp, need));
+            env->tmp_bytes = need;
+        }
+        int32_t *d_st = (int32_t *)env->d_tmp;
+        int32_t *d_len = d_st + (size_t)m * 28;
+        int8_t *d_seq = (int8_t *)(d_len + m);
+        hipLaunchKernelGGL(rows_read_kernel, grid1(m, 128), dim3(128), 0, nullptr, env->v.rows, env->v.seqs, 0ll, m, d_st, d_seq, d_len);
+        if (h_states28) HIPCHK(hipMemcpy(h_states28, d_st, (size_t)m * 28 * 4, hipMemcpyDeviceToHost));
+        if (h_len) HIPCHK(hipMemcpy(h_len, d_len, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (h_seq) HIPCHK(hipMemcpy(h_seq, d_seq, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipGetLastError());
+    return (int64_t)C;
 }
 
 int bgamd_env_set_dice(bgamd_env *env, const int32_t *d_dice, void *stream)

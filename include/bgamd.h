@@ -112,6 +112,28 @@ int bgamd_env_get_dice(bgamd_env *env, int32_t *d_dice /*[n,2]*/, void *stream);
  * repeated calls draw fresh dice (the scalar Game surface), 0 leaves ply to the step functions. */
 int bgamd_env_roll(bgamd_env *env, int advance_ply, void *stream);
 
+/* ---- the scalar Game surface with HOST arguments, for ONE-LANE envs (n_games == 1): what a compiled binding of the
+ * reference's module calls per method of bindings.cpp:62-93 (backgammon-engine_amd/pybind/backgammon_env_pybind.cpp is that
+ * binding; the Python package's Game uses the same entry points).  Plain ints and host pointers in and out; each call
+ * stages its arguments on the device, runs the same kernels as the vectorised entry points and synchronises.
+ *   snapshot   : h_out[32] = state28 | turn | die1 | die2 | flags (as bgamd_env_get_flags)  -- getGameBoard, getTurn,
+ *                getJailedCount, getBornOffCount, get_last_dice, is_game_over
+ *   set_state  : h_state28 (or NULL = keep the board) and turn (-1 = keep)                    -- setGameBoard, setBorneOffPieces, setTurn
+ *   set_dice / roll (roll draws the lane's next Philox dice and returns them)                -- setDice, roll_dice
+ *   legal_moves: returns the number of (origin, dest) pairs written to h_pairs[26][2]         -- legalMoves (game.cpp:80-105)
+ *   try_move   : returns 0 = moved, 1..7 = the reference's message in source order            -- tryMove (game.cpp:573-663)
+ *   enumerate  : returns the number C of sequences of legalTurnSequences / evaluateTurnSequences (game.cpp:134-222) in
+ *                reference order and fills the first min(C, cap) rows of h_states28[.][28], h_seq[.][4][2], h_len[.]
+ *                (any may be NULL); call with cap = 0 for the count alone */
+int bgamd_game_snapshot(bgamd_env *env, int32_t h_out[32]);
+int bgamd_game_set_state(bgamd_env *env, const int32_t *h_state28, int turn);
+int bgamd_game_set_dice(bgamd_env *env, int d1, int d2);
+int bgamd_game_roll(bgamd_env *env, int32_t h_dice[2]);
+int bgamd_game_legal_moves(bgamd_env *env, int player, int die, int8_t *h_pairs);
+int bgamd_game_try_move(bgamd_env *env, int player, int dice, int origin, int dest);
+int64_t bgamd_game_enumerate(bgamd_env *env, int player, int d1, int d2, int32_t *h_states28, int8_t *h_seq, int32_t *h_len,
+                             int64_t cap);
+
 /* ---- enumeration: Game::evaluateTurnSequences for every lane (game.cpp:193-222) -----------
  * Fills the env's candidate arena in REFERENCE ORDER (duplicates kept) for the lanes' current
  * turn and dice, or for the explicit (player, d1, d2) arguments of the reference call.  Afterwards:

@@ -436,11 +436,20 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
 
 # ---- the scalar drop-in surface: whole games in the shape of the reference's loop ------------------------------------------
 
-def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
-    """24 complete games through bg.Game exactly as train.py:103-121 / benchmark.py:54-61 drive the reference module:
+def _pybind_module():
+    from test_abi_cpu import _load_pybind_module
+    return _load_pybind_module()
+
+
+@pytest.mark.parametrize("surface", ["python_package", "pybind11_module"])
+def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface):
+    """24 complete games through the scalar drop-in surface -- the Python package's Game and the compiled pybind11 module
+    (the reference's own binding technology over the same C ABI) -- exactly as train.py:103-121 / benchmark.py:54-61 drive the reference module:
     setDice -> evaluateTurnSequences -> pick by index -> tryMove x len -> is_game_over -> setTurn, compared turn by
     turn with fixture G3 (played by the unmodified reference on the same injected dice and choices).  Reports the
     config-1 throughput of this surface."""
+    if surface == "pybind11_module":
+        bg = _pybind_module()
     g = np.load(os.path.join(golden_dir, "g3_random_trajectories.npz"))
     rows = g["rows"]
     p1, p2 = bg.Player("White", bg.PlayerType.PLAYER1), bg.Player("Black", bg.PlayerType.PLAYER2)
@@ -454,10 +463,10 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
         for t in range(len(r)):
             turn, d1, d2, C, k = int(r[t, 30]), int(r[t, 31]), int(r[t, 32]), int(r[t, 33]), int(r[t, 34])
             assert game.getTurn() == turn
-            assert game.getGameBoard() == list(r[t, 2:26])
+            assert list(game.getGameBoard()) == list(r[t, 2:26])
             assert [game.getJailedCount(0), game.getJailedCount(1), game.getBornOffCount(0), game.getBornOffCount(1)] == list(r[t, 26:30])
             game.setDice(d1, d2)
-            assert game.get_last_dice() == [d1, d2]
+            assert list(game.get_last_dice()) == [d1, d2]
             seqs, states = game.evaluateTurnSequences(turn, d1, d2)
             assert len(seqs) == C and states.shape == (C, 28)
             if C:
@@ -465,8 +474,8 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
                 for o, d in seqs[k]:
                     ok, msg = game.tryMove(pl, abs(o - d), o, d)
                     assert ok and msg == ""
-                assert game.getGameBoard() + [game.getJailedCount(0), game.getJailedCount(1), game.getBornOffCount(0),
-                                              game.getBornOffCount(1)] == list(states[k])
+                assert list(game.getGameBoard()) + [game.getJailedCount(0), game.getJailedCount(1), game.getBornOffCount(0),
+                                                    game.getBornOffCount(1)] == list(states[k])
             over, winner = game.is_game_over()
             assert int(over) == r[t, 35] and (not over or winner == r[t, 36])
             turns += 1
@@ -475,7 +484,7 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
                 break
             game.setTurn(1 - turn)
     dt = time.time() - t0
-    print("scalar surface (config 1): %d turns of 24 games in %.2f s = %.0f env steps/s" % (turns, dt, turns / dt))
+    print("scalar surface (config 1, %s): %d turns of 24 games in %.2f s = %.0f env steps/s" % (surface, turns, dt, turns / dt))
     # clone(): independent copy, cheap (pooled one-lane envs), last_dice reset to [1, 1] (game.cpp:68-77)
     game = bg.Game(1)
     game.setDice(3, 4)
@@ -487,8 +496,9 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir):
     for _ in range(200):
         c = game.clone()
     dt_pool = (time.time() - t0) / 200
-    assert c.getGameBoard() == game.getGameBoard() and c.getTurn() == 1 and c.get_last_dice() == [1, 1]
-    assert c.tryMove(p2, 1, 6, 5)[0] and game.getGameBoard() == START and c.getGameBoard() != START
+    assert list(c.getGameBoard()) == list(game.getGameBoard()) and c.getTurn() == 1 and list(c.get_last_dice()) == [1, 1]
+    assert c.tryMove(p2, 1, 6, 5)[0] and list(game.getGameBoard()) == START and list(c.getGameBoard()) != START
+    assert c.tryMove(p2, 5, 6, 12) == (False, "Cannot move in that direction.") and c.getPieces().numJailed(0) == 0
     print("Game.clone(): %.2f ms each while the pool fills, %.3f ms from the pool" % (1e3 * dt_first / 50, 1e3 * dt_pool))
     assert dt_pool < 0.01
 
