@@ -436,20 +436,23 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
 
 # ---- the scalar drop-in surface: whole games in the shape of the reference's loop ------------------------------------------
 
-def _pybind_module():
-    from test_abi_cpu import _load_pybind_module
-    return _load_pybind_module()
+def test_pybind_module_full_games_vs_g3():
+    """The compiled pybind11 module (the reference's own binding technology over the same C ABI) plays fixture G3's first 24
+    games turn for turn, answers cppsrc/tests.cpp's known answers, clones and reports the reference's error strings -- in a
+    process of its own (tests/pybind_driver.py: one extension module per name and process)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pybind_driver.py"), "games", "24"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    tag, turns, dt = r.stdout.split()[-3:]
+    assert tag == "OK" and int(turns) == 2116
+    print("scalar surface (config 1, pybind11 module): %s turns of 24 games in %s s = %.0f env steps/s" % (turns, dt, int(turns) / float(dt)))
 
 
-@pytest.mark.parametrize("surface", ["python_package", "pybind11_module"])
-def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface):
-    """24 complete games through the scalar drop-in surface -- the Python package's Game and the compiled pybind11 module
-    (the reference's own binding technology over the same C ABI) -- exactly as train.py:103-121 / benchmark.py:54-61 drive the reference module:
+def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package"):
+    """24 complete games through the Python package's scalar Game exactly as train.py:103-121 / benchmark.py:54-61 drive the reference module:
     setDice -> evaluateTurnSequences -> pick by index -> tryMove x len -> is_game_over -> setTurn, compared turn by
     turn with fixture G3 (played by the unmodified reference on the same injected dice and choices).  Reports the
     config-1 throughput of this surface."""
-    if surface == "pybind11_module":
-        bg = _pybind_module()
     g = np.load(os.path.join(golden_dir, "g3_random_trajectories.npz"))
     rows = g["rows"]
     p1, p2 = bg.Player("White", bg.PlayerType.PLAYER1), bg.Player("Black", bg.PlayerType.PLAYER2)
