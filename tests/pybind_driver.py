@@ -50,6 +50,9 @@ def games(n):
     g = np.load(os.path.join(ROOT, "tests", "golden", "g3_random_trajectories.npz"))
     rows = g["rows"]
     p1, p2 = bg.Player("White", bg.PlayerType.PLAYER1), bg.Player("Black", bg.PlayerType.PLAYER2)
+    warm = bg.Game(0)                                         # HIP start-up and the first launches are not the surface's throughput
+    warm.legalTurnSequences(0, 3, 1)
+    del warm
     turns, t0 = 0, time.time()
     for lane in range(n):
         r = rows[rows[:, 0] == lane]
