@@ -415,6 +415,20 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)n_rows);
     const long long n_tiles = (n_rows + 63) >> 6;
     const int lane = threadIdx.x & 63;
+    // Row -> lane: 16 CONSECUTIVE rows of a tile sit on the 16 lanes the LDS serves together for a ds_read_b128 (the lane groups
+    // are {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32: MI355X_MICROARCH.md).  Neighbouring rows are siblings of one
+    // turn and ask for the same or for neighbouring W1^T rows, which broadcast or fall into different banks; rows of different
+    // games collide at random.  rl = the lane's row inside its tile, inv = the lane that holds row `lane` (same-box A/B against
+    // row = lane: value net 0.0808 -> 0.0796 ms).
+    int rl, inv;
+    {
+        const int hl = lane & 31;
+        const int g = (hl < 4 || (hl >= 12 && hl < 16) || (hl >= 20 && hl < 28)) ? 0 : 1;
+        const int k = hl < 4 ? hl : hl < 12 ? hl - 4 : hl < 16 ? hl - 8 : hl < 20 ? hl - 8 : hl < 28 ? hl - 12 : hl - 16;
+        rl = (lane & 32) + 16 * g + k;
+        const int R = lane, gg = (R >> 4) & 1, kk = R & 15;
+        inv = (R & 32) + (gg == 0 ? (kk < 4 ? kk : kk < 8 ? 8 + kk : 12 + kk) : (kk < 8 ? 4 + kk : kk < 12 ? 8 + kk : 16 + kk));
+    }
     // A tile's cost follows its longest delta list (a doubles turn costs twice a plain one), so the 64-row tiles of a
     // workgroup's contiguous range go to whichever wave is free (LDS ticket) instead of a fixed stride per wave
     // (tiles of a workgroup: b, b + G, b + 2G, ... -- the arena holds runs of light rows (non-doubles turns) and runs of
@@ -434,15 +448,15 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
     uint2 nxi = make_uint2(0u, 0u);
     long long tile = grab();
-    if (tile < t_hi && tile * 64 + lane < n_rows) {
-        const long long r0 = tile * 64 + lane;
+    if (tile < t_hi && tile * 64 + rl < n_rows) {
+        const long long r0 = tile * 64 + rl;
         nx0 = rows[2 * r0]; nx1 = rows[2 * r0 + 1]; nxi = info[r0];
     }
     // ... and so is its game's root row (issued during the last pass of the tile before)
     uint4 nr0 = root_rows[2 * (long long)nxi.x], nr1 = root_rows[2 * (long long)nxi.x + 1];
     while (tile < t_hi) {
         const long long next_tile = grab();
-        const long long row = tile * 64 + lane;
+        const long long row = tile * 64 + rl;
         const bool valid = row < n_rows;
         const uint2 inf = nxi;                             // (0, 0) for a padding lane: game 0, harmless
         const uint4 r0 = nr0, r1 = nr1;
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         const uint32_t q[8] = {valid ? r0.x & ~TURN_BIT : 0u, valid ? r0.y : 0u, valid ? r0.z : 0u, valid ? r0.w : 0u,
                                valid ? r1.x : 0u, valid ? r1.y : 0u, valid ? r1.z : 0u, valid ? r1.w : 0u};
         {
-            const long long nrow = next_tile * 64 + lane;
+            const long long nrow = next_tile * 64 + rl;
             nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0); nxi = make_uint2(0u, 0u);
             if (next_tile < t_hi && nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
         }
@@ -577,7 +591,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         {
             const float v = fast_sigmoid(sum + b2);
             if (valid) values[row] = v;
-            best_atomic_max(best, inf.x, v, inf.y, valid, 64);
+            // the per-game maximum runs over neighbouring ROWS: back to row order first
+            best_atomic_max(best, __shfl(inf.x, inv, 64), __shfl(v, inv, 64), __shfl(inf.y, inv, 64), __shfl((int)valid, inv, 64) != 0, 64);
         }
         tile = next_tile;
     }
