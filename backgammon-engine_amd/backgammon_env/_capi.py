@@ -81,6 +81,7 @@ SYMBOLS = [
     ("bgamd_td_replay", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_double, C.c_float, _P]),
     ("bgamd_td_stats", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("bgamd_td_active_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("bgamd_td_written_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("bgamd_td_time", C.c_int, [_P, C.c_int]),
     ("bgamd_td_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]

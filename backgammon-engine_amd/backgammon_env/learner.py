@@ -163,6 +163,13 @@ class DeviceTDLambdaLearner:
         self._capi.check(self._lib.bgamd_td_active_columns(self._h, self._C.byref(c)), "td_active_columns")
         return int(c.value)
 
+    def written_columns(self):
+        """... of the W1 trace columns written (lazily scaled traces: only where x_j != 0, except on the passes that fold the
+        scale back in)."""
+        c = self._C.c_uint64()
+        self._capi.check(self._lib.bgamd_td_written_columns(self._h, self._C.byref(c)), "td_written_columns")
+        return int(c.value)
+
     def trace_kernel_times(self):
         C = self._C
         ms, n, gs = C.c_double(), C.c_uint64(), C.c_uint64()

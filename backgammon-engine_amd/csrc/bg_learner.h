@@ -24,6 +24,13 @@
 // floats), every game carries the bit mask of its ever-active features, and the pass touches only those columns: λ·0 + 0 is
 // never read, never computed, never written.  Same arithmetic on the same numbers in the same order: results are
 // bit-identical to the dense pass (BGAMD_TD_DENSE=1 keeps it for the test that says so), at ~0.37 of its HBM traffic.
+//
+// Lazily scaled traces (round 2, what runs unless BGAMD_TD_LAZY=0): every game of a replay starts at t = 0 and decays by the
+// same λ per step, so the stored trace is ê = e / c with ONE host-side scale c = Π λ for all games.  e ← λ e + ∇ becomes
+// ê ← ê + ∇ / c: a column whose feature is zero in s_t has ∇ = 0 and is READ (Σ_g coef_g c ê_g needs it) but NOT WRITTEN --
+// ~30 of the ~72 active columns of a game are written per step.  When c falls below 2^-40 (every 78 steps at λ = 0.7) one
+// ordinary pass folds it back in (ê ← c ê + ∇, c = 1); with λ so small that every step would, this IS the ordinary pass.
+// Same real numbers, different rounding (fp32 relative 1e-7 per term): the parity tests' bounds hold unchanged.
 #pragma once
 #include "bg_board.h"
 #include "bg_eval.h"
@@ -71,6 +78,8 @@ struct TdView {
     uint32_t *anew;                      // [max_games][TD_MASK_WORDS] ... for the first time at the current step (trace column = 0: not read)
     unsigned int *act_cols;              // [max_games] Σ over the game's steps of its active W1 trace columns since begin (traffic report;
                                          //   per game: a single counter would be one same-address atomic per block and step)
+    unsigned int *wr_cols;               // [max_games] ... of the W1 trace columns WRITTEN (lazily scaled traces: x_j != 0 or newly active)
+    int full_step;                       // the step at hand is an ordinary pass: every active column is written
     int dense;                           // BGAMD_TD_DENSE=1: every column active from the first step (the dense pass)
     long long T, n_lanes, n_games;
 };
@@ -127,6 +136,7 @@ __global__ void td_gather_kernel(TdView v)
     v.gmeta[i] = make_int4(lane, len, v.p1_won[lane] ? 1 : 0, 0);
     v.sq[i] = 0.0;
     v.act_cols[i] = 0u;
+    v.wr_cols[i] = 0u;
 }
 
 // TD_GB games x {s_t, s_{t+1}} per workgroup of 128 threads (2 for small rounds: a shorter FMA chain per thread and
@@ -138,7 +148,7 @@ template <int TD_GB, bool PRE>
 __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, long long n_active, double alpha)
 {
     constexpr int NR = 2 * TD_GB;                         // rows: [s][game]
-    __shared__ unsigned int s_colsg[TD_GB];
+    __shared__ unsigned int s_colsg[TD_GB], s_wrg[TD_GB];
     __shared__ __attribute__((aligned(16))) float xs[PRE ? 1 : N_IN][NR];
     __shared__ uint32_t srow[TD_GB][8];                   // the 32-byte row of s_t of every game of the block
     __shared__ uint32_t smask[TD_GB][TD_MASK_WORDS];
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         }
     }
     const float w2 = v.theta[TD_OFF_W2 + n];
-    if (tid < TD_GB) s_colsg[tid] = 0;
+    if (tid < TD_GB) { s_colsg[tid] = 0; s_wrg[tid] = 0; }
     __syncthreads();
     // ---- ever-active feature masks of the games: thread = (game, board point | tail) ORs its 8 (6) "x_j != 0" bits into the
     //      game's mask words; the trace pass touches only these columns ----
@@ -234,11 +244,13 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         if (i < n_active) {
             uint32_t now = smask[g][wd];
             const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);     // 198 = 6 * 32 + 6
+            const uint32_t nz = now & valid;
             if (v.dense) now = valid;
             const uint32_t old = t == 0 ? 0u : v.amask[i * TD_MASK_WORDS + wd];
             v.amask[i * TD_MASK_WORDS + wd] = old | now;
             v.anew[i * TD_MASK_WORDS + wd] = now & ~old;
             atomicAdd(&s_colsg[g], (unsigned int)__popc(old | now));
+            atomicAdd(&s_wrg[g], (unsigned int)__popc(v.full_step ? (old | now) : (nz | (now & ~old))));
         }
     }
 
@@ -306,7 +318,10 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         if (n < 8) f[TD_F_ROW + n] = __uint_as_float(srow[gq][n]);
         if (n == 8) f[TD_F_G] = g;
     }
-    if (tid < TD_GB && i0 + tid < n_active) v.act_cols[i0 + tid] += s_colsg[tid];  // (the barriers above ordered the LDS adds)
+    if (tid < TD_GB && i0 + tid < n_active) {                                      // (the barriers above ordered the LDS adds)
+        v.act_cols[i0 + tid] += s_colsg[tid];
+        v.wr_cols[i0 + tid] += s_wrg[tid];
+    }
 }
 
 // Epilogue of the matrix-pipe forward pass, ONE WAVE PER GAME (4 games per 256-thread block, no LDS, no block barrier): lane l
@@ -350,16 +365,19 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     bits |= __shfl_xor(bits, 1, 64);
     bits |= __shfl_xor(bits, 2, 64);
     uint32_t now = __shfl(bits, 4 * (lane & 7), 64);           // lane w < 7 takes word w from lane 4 w
+    unsigned int wr = 0;
     if (lane < TD_MASK_WORDS) {
         const uint32_t valid = lane < 6 ? 0xFFFFFFFFu : (lane == 6 ? 0x3Fu : 0u);
-        now = v.dense ? valid : (now & valid);
+        const uint32_t nz = now & valid;
+        now = v.dense ? valid : nz;
         v.amask[i * TD_MASK_WORDS + lane] = old | now;
         v.anew[i * TD_MASK_WORDS + lane] = now & ~old;
+        wr = (unsigned int)__popc(v.full_step ? (old | now) : (nz | (now & ~old)));
     }
     unsigned int cols = lane < TD_MASK_WORDS ? (unsigned int)__popc(old | now) : 0u;
 #pragma unroll
-    for (int m = 4; m >= 1; m >>= 1) cols += __shfl_xor(cols, m, 64);
-    if (lane == 0) v.act_cols[i] += cols;
+    for (int m = 4; m >= 1; m >>= 1) { cols += __shfl_xor(cols, m, 64); wr += __shfl_xor(wr, m, 64); }
+    if (lane == 0) { v.act_cols[i] += cols; v.wr_cols[i] += wr; }
 }
 
 // grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace (internal order); `ng` games per group.
@@ -367,8 +385,12 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
 // dense tail b1 | W2 | b2), for every game of its group: a W1 column that is not active in a game is skipped for that game
 // (no load, no store, nothing to add), one that became active at this step is written without being read.
 template <bool FIRST>
-__global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, long long n_active, int ng, float lambda)
+__global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, long long n_active, int ng, float emul, float ginv,
+                                                                    float cmul, int full)
 {
+    // stored trace ê, scale c (host): ê_new = emul · ê_old + ginv · ∇, update += coef · cmul · ê_new.
+    //   ordinary pass (full = 1): emul = λ c_old, ginv = 1, cmul = 1 (c_old = 1 with BGAMD_TD_LAZY=0: e ← λ e + ∇ to the bit)
+    //   lazy pass     (full = 0): emul = 1, ginv = 1 / c, cmul = c; a column with x_j = 0 keeps its bits and is not stored
     // a game's factor row: its 32-byte row (x_j is decoded from it) | db1 | g·h | g
     constexpr int L_DB1 = TD_F_DB1, L_GH = TD_F_GH, L_G = TD_F_G, L_LD = TD_FLD;
     __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][L_LD];
@@ -407,7 +429,7 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
             const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
             float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
             for (int q = tid; q < m * (TD_FLD / 4); q += TD_TRACE_THREADS) dst[q] = src[q];
-            if (tid < m) cs[tid] = v.coef[gb + tid];
+            if (tid < m) cs[tid] = v.coef[gb + tid] * cmul;
             if (tid < m * TD_MASK_WORDS) {
                 (&ms[0][0])[tid] = v.amask[gb * TD_MASK_WORDS + tid];
                 (&ns[0][0])[tid] = v.anew[gb * TD_MASK_WORDS + tid];
@@ -444,12 +466,14 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
                 // (decoded per thread: one decode per (slice, game) shared through LDS costs a third barrier per chunk and
                 //  was slower, 98.1 vs 96.2 ms per 65 536-game replay)
                 const float xj = is_w1 ? td_feature_value(reinterpret_cast<const uint32_t *>(&fs[q][TD_F_ROW]), jw) : 1.0f;
-                x.x = fmaf(lambda, x.x, fs[q][ia[0]] * (is_w1 ? xj : xfix[0]));
-                x.y = fmaf(lambda, x.y, fs[q][ia[1]] * (is_w1 ? xj : xfix[1]));
-                x.z = fmaf(lambda, x.z, fs[q][ia[2]] * (is_w1 ? xj : xfix[2]));
-                x.w = fmaf(lambda, x.w, fs[q][ia[3]] * (is_w1 ? xj : xfix[3]));
-                td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
-                __builtin_nontemporal_store(x, ep);
+                x.x = fmaf(emul, x.x, (fs[q][ia[0]] * (is_w1 ? xj : xfix[0])) * ginv);
+                x.y = fmaf(emul, x.y, (fs[q][ia[1]] * (is_w1 ? xj : xfix[1])) * ginv);
+                x.z = fmaf(emul, x.z, (fs[q][ia[2]] * (is_w1 ? xj : xfix[2])) * ginv);
+                x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (is_w1 ? xj : xfix[3])) * ginv);
+                if (full || !is_w1 || xj != 0.0f || !((rd >> q) & 1u)) {      // (not read = activated at this step: written whatever x_j is)
+                    td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
+                    __builtin_nontemporal_store(x, ep);
+                }
                 const float cf = cs[q];
                 acc.x = fmaf(cf, x.x, acc.x);
                 acc.y = fmaf(cf, x.y, acc.y);

@@ -1589,6 +1589,8 @@ struct bgamd_td {
     bool has_weights = false, begun = false;
     int n_cu = 256;
     long long mfma_min = 3072;             // running games from which the forward pass goes to the matrix pipe (BGAMD_TD_MFMA_MIN)
+    bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
+    double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
     uint64_t updates = 0;
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -1643,6 +1645,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.amask, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.anew, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.act_cols, (size_t)max_games * 4);
+    TDALLOC(v.wr_cols, (size_t)max_games * 4);
     TDALLOC(v.wl3, 3 * EVAL16_W_BYTES);
     TDALLOC(v.lut, EVAL16_LUT_BYTES);
     TDALLOC(v.hid, (size_t)max_games * 2 * N_HID * 4);
@@ -1659,7 +1662,9 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
         td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 3072;
     }
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
+    td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
+    HIPCHK(hipMemset(v.wr_cols, 0, (size_t)max_games * 4));
     HIPCHK(hipMemset(v.theta, 0, TD_LD * 4));
     HIPCHK(hipMemset(v.sq, 0, (size_t)max_games * 8));
     *out = td;
@@ -1672,7 +1677,7 @@ int bgamd_td_destroy(bgamd_td *td)
     hipSetDevice(td->device);
     hipDeviceSynchronize();
     TdView &v = td->v;
-    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wl3, v.lut, v.hid};
+    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wr_cols, v.wl3, v.lut, v.hid};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
     delete td;
@@ -1730,6 +1735,17 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         if (d_update) HIPCHK(hipMemsetAsync(d_update, 0, (size_t)TD_P * 4, s));
         return BGAMD_OK;
     }
+    // the scale of the stored traces (bg_learner.h): t = 0 writes ∇ at c = 1; afterwards c <- λ c, folded back in by an ordinary
+    // pass when it leaves [2^-40, 2^40] (λ > 1 is the caller's business, but it must not overflow either)
+    float emul = lambda, ginv = 1.0f, cmul = 1.0f;
+    int full = 1;
+    if (t == 0) td->scale = 1.0;
+    else {
+        const double c = (double)lambda * td->scale;
+        if (td->lazy && c >= 0x1p-40 && c <= 0x1p40) { td->scale = c; emul = 1.0f; ginv = (float)(1.0 / c); cmul = (float)c; full = 0; }
+        else { emul = (float)c; td->scale = 1.0; }
+    }
+    td->v.full_step = full;
     const TdView &v = td->v;
     if (n_active >= td->mfma_min) {
         // the [2 G x 198] · [198 x 128] product of the step on the matrix pipe (exact bf16 x 3 split of fc1.weight, fp32
@@ -1761,10 +1777,10 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     }
     if (t == 0)
         hipLaunchKernelGGL(td_trace_kernel<true>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
-                           (int)ng, lambda);
+                           (int)ng, emul, ginv, cmul, 1);
     else
         hipLaunchKernelGGL(td_trace_kernel<false>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
-                           (int)ng, lambda);
+                           (int)ng, emul, ginv, cmul, full);
     if (td->timing) {
         HIPCHK(hipEventRecord(e1, s));
         td->trace_launches++;
@@ -1821,6 +1837,19 @@ int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns)
     HIPCHK(hipDeviceSynchronize());
     std::vector<unsigned int> c((size_t)td->v.n_games);
     if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.act_cols, c.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (unsigned int x : c) tot += x;
+    *h_columns = tot;
+    return BGAMD_OK;
+}
+
+int bgamd_td_written_columns(bgamd_td *td, uint64_t *h_columns)
+{
+    if (!td || !h_columns) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned int> c((size_t)td->v.n_games);
+    if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.wr_cols, c.size() * 4, hipMemcpyDeviceToHost));
     uint64_t tot = 0;
     for (unsigned int x : c) tot += x;
     *h_columns = tot;

@@ -267,6 +267,11 @@ int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates);
  * were touched (of 198; a column = 128 floats, read + written).  BGAMD_TD_DENSE=1 in the environment at bgamd_td_create
  * keeps every column active (the dense pass: same results bit for bit, 198 columns per update).  Synchronises. */
 int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns);
+/* ... and of the columns that were WRITTEN.  The stored trace is e / c with one scale c = Π λ for all games of the replay
+ * (train.py:150-158's e <- λ e + ∇ becomes ê <- ê + ∇ / c), so a column whose feature is zero in s_t is read but not written;
+ * c is folded back in by an ordinary pass when it leaves [2^-40, 2^40].  BGAMD_TD_LAZY=0 at bgamd_td_create: every step is an
+ * ordinary pass (written = active).  Synchronises. */
+int bgamd_td_written_columns(bgamd_td *td, uint64_t *h_columns);
 /* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1) */
 int bgamd_td_time(bgamd_td *td, int enable);
 int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps);

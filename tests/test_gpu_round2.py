@@ -506,6 +506,37 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     assert dt_pool < 0.01
 
 
+def test_lazily_scaled_traces_equal_the_ordinary_pass(bg, weights):
+    """The stored trace is e / c with one scale c = Π λ per replay, so columns whose feature is zero at a step are read but
+    not written.  BGAMD_TD_LAZY=0 runs e <- λ e + ∇ on every column at every step (round 1's arithmetic to the bit).  Same
+    log: the weights agree to fp32 rounding, for a λ whose scale is folded back in every ~100 steps and for one that needs
+    it every ~9 steps; fewer columns are written than read."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
+    n = 2048
+    env = bg.VecGame(n, seed=77)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    for lam in (0.75, 0.04):
+        out = {}
+        for mode in ("lazy", "ordinary"):
+            if mode == "ordinary":
+                os.environ["BGAMD_TD_LAZY"] = "0"
+            try:
+                L = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=lam)
+            finally:
+                os.environ.pop("BGAMD_TD_LAZY", None)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=0.02)
+            out[mode] = (_np(L.theta).astype(np.float64), sq, cnt, L.active_columns(), L.written_columns())
+        moved = np.abs(out["ordinary"][0] - weights).max()
+        err = np.abs(out["lazy"][0] - out["ordinary"][0]).max()
+        print("lambda %.2f: max |theta_lazy - theta_ordinary| = %.3g (weights moved by up to %.3g); columns read %d, written %d (ordinary: %d)"
+              % (lam, err, moved, out["lazy"][3], out["lazy"][4], out["ordinary"][4]))
+        assert moved > 1e-3 and err < 2e-6
+        assert abs(out["lazy"][1] - out["ordinary"][1]) <= 1e-5 * out["ordinary"][1] and out["lazy"][2] == out["ordinary"][2]
+        assert out["ordinary"][4] == out["ordinary"][3] == out["lazy"][3]
+        assert out["lazy"][4] < 0.75 * out["lazy"][3]
+
+
 def test_sparse_traces_equal_dense_traces_bit_for_bit(bg, weights):
     """The learner touches only the W1 trace columns of features that have been non-zero in a game so far (the others
     are exactly zero).  BGAMD_TD_DENSE=1 makes every column active from the first step -- the dense pass.  Same log,

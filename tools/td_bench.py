@@ -17,10 +17,10 @@ for n in [int(x) for x in (sys.argv[1:] or ["512", "4096", "16384"])]:
     sq, cnt = L.replay_rows(rows, lengths, won, batch_scale=24.0 / n)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ms, nl, gs = L.trace_kernel_times()
-    cols = L.active_columns()
-    moved = (cols * 128 + gs * 257) * 8                 # bytes read + written: active W1 columns + the dense b1 | W2 | b2 tail
+    cols, wcols = L.active_columns(), L.written_columns()
+    moved = ((cols + wcols) * 128 + 2 * gs * 257) * 4   # bytes read + written: active / written W1 columns + the dense b1 | W2 | b2 tail
     print(f"n={n} T={rows.shape[0]} updates={cnt} device replay {dt*1e3:.1f} ms -> {cnt/dt/1e6:.2f} M updates/s | trace kernel {ms:.1f} ms "
-          f"({nl} launches): {cols/max(gs,1):.1f} of 198 W1 columns active per update, {moved/ms/1e6:.0f} GB/s moved "
+          f"({nl} launches): {cols/max(gs,1):.1f} of 198 W1 columns read, {wcols/max(gs,1):.1f} written per update, {moved/ms/1e6:.0f} GB/s moved "
           f"(dense-equivalent {gs*204808/ms/1e6:.0f} GB/s)", flush=True)
     if n <= 4096:
         X = env.encode_rows(rows)
