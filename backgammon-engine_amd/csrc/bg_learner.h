@@ -48,7 +48,10 @@ constexpr int TD_SLICES = (TD_LD / 4 + TD_TRACE_THREADS - 1) / TD_TRACE_THREADS;
 #define BG_TD_CHUNK 8
 #endif
 constexpr int TD_CHUNK = BG_TD_CHUNK;    // games staged in LDS at a time by the trace kernel
-constexpr int TD_MAX_GROUPS = 256;
+#ifndef BG_TD_MAX_GROUPS
+#define BG_TD_MAX_GROUPS 256
+#endif
+constexpr int TD_MAX_GROUPS = BG_TD_MAX_GROUPS;
 constexpr int TD_MASK_WORDS = 8;         // 198 feature bits in 7 words, padded to 32 B per game
 // INTERNAL order of a trace row / partial-sum row (the parameter order of theta is fc1.weight[n][j] | b1 | W2 | b2):
 //   [j * 128 + n] = W1[n][j] for j < 198 (feature-major: a column of W1 is 512 contiguous bytes), then b1, W2, b2 at the
@@ -483,6 +486,152 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
         }
     }
     if (in_row) *reinterpret_cast<float4 *>(v.partial + (long long)blockIdx.y * TD_LD + p0) = acc;
+}
+
+// The same pass for LARGE rounds: one workgroup of 512 threads owns the WHOLE trace row (25 664 floats = 13 float4 per thread,
+// its partial sums in 52 registers) for a strided share of the running games, so a game's factor row is staged once per
+// step instead of once per 1 024-float slice (26 x: at 65 536 games 1.85 GB per step through the L2s next to the 3.3 GB of
+// trace traffic), and a thread's loads of a game (its active columns among 13) go out together, for two games at a time.
+// Thread tid: hidden units 4 (tid & 31) .. + 3 of the columns j = 16 k + (tid >> 5), k = 0..12 -- side and thermometer level of
+// its features are the same for every k, only the board point moves (2 k + (tid >> 8) + 1), so x_j is one shift of a word formed
+// once per game.  k = 12: columns 192..197 (tid < 192), then b1 | W2 | b2 | padding (tid 192..271).
+// Same arithmetic per element as td_trace_kernel; the partial sums group the games differently (sums differ by rounding).
+#ifndef BG_TD_WIDE_W
+#define BG_TD_WIDE_W 512
+#endif
+#ifndef BG_TD_WIDE_BPC
+#define BG_TD_WIDE_BPC 1
+#endif
+constexpr int TD_WIDE_THREADS = BG_TD_WIDE_W;                 // 512 or 1024
+constexpr int TD_WIDE_KL = 6144 / TD_WIDE_THREADS;            // the k of the tail group (columns 192..197 | b1 | W2 | b2)
+constexpr int TD_WIDE_K = TD_WIDE_KL + 1;
+constexpr int TD_WIDE_CPG = TD_WIDE_THREADS / 32;             // columns per k
+#ifndef BG_TD_WIDE_GPI
+#define BG_TD_WIDE_GPI 2
+#endif
+template <bool FIRST>
+__global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide_kernel(TdView v, long long n_active, float emul, float ginv, float cmul, int full)
+{
+    constexpr int GPI = BG_TD_WIDE_GPI;
+    __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][TD_FLD];
+    __shared__ float cs[TD_CHUNK];
+    __shared__ uint32_t ms[TD_CHUNK][TD_MASK_WORDS], ns[TD_CHUNK][TD_MASK_WORDS];
+    const int tid = threadIdx.x;
+    const int c = tid >> 5;                                   // column inside a group of TD_WIDE_CPG
+    const int n0 = (tid & 31) * 4;                            // hidden units n0 .. n0 + 3
+    const int base = 4 * ((c >> 2) & 1), level = c & 3;       // of the board features j = CPG k + c, k < KL
+    const int pos0 = (c >> 3) + 1;                            // board position of column k: pos0 + CPG k / 8
+    // k = 12: tail columns / dense tail
+    const bool t_w1 = tid < 192, t_in = tid < 272;
+    int ia[4];
+    float xfix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = (TD_WIDE_KL * TD_WIDE_THREADS + tid) * 4 + u;
+        xfix[u] = 1.0f;
+        if (p < TD_OFF_B1) ia[u] = TD_F_DB1 + (p & (N_HID - 1));
+        else if (p < TD_OFF_W2) ia[u] = TD_F_DB1 + (p - TD_OFF_B1);
+        else if (p < TD_OFF_B2) ia[u] = TD_F_GH + (p - TD_OFF_W2);
+        else if (p == TD_OFF_B2) ia[u] = TD_F_G;
+        else { ia[u] = TD_F_G; xfix[u] = 0.0f; }
+    }
+    td_f32x4 acc[TD_WIDE_K];
+#pragma unroll
+    for (int k = 0; k < TD_WIDE_K; ++k) acc[k] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long long chunk = blockIdx.x; chunk * TD_CHUNK < n_active; chunk += gridDim.x) {
+        const long long gb = chunk * TD_CHUNK;
+        const long long left = n_active - gb;
+        const int m = left < TD_CHUNK ? (int)left : TD_CHUNK;
+        __syncthreads();
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
+            float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
+            for (int q = tid; q < m * (TD_FLD / 4); q += TD_WIDE_THREADS) dst[q] = src[q];
+            if (tid < m) cs[tid] = v.coef[gb + tid] * cmul;
+            if (tid < m * TD_MASK_WORDS) {
+                (&ms[0][0])[tid] = v.amask[gb * TD_MASK_WORDS + tid];
+                (&ns[0][0])[tid] = v.anew[gb * TD_MASK_WORDS + tid];
+            }
+        }
+        __syncthreads();
+        for (int q0 = 0; q0 < m; q0 += GPI) {
+            uint32_t act[GPI], rd[GPI];
+            td_f32x4 ev[GPI][TD_WIDE_K];
+#pragma unroll
+            for (int u = 0; u < GPI; ++u) {
+                const int q = q0 + u;
+                act[u] = 0; rd[u] = 0;
+                if (q < m) {
+#pragma unroll
+                    for (int k = 0; k < TD_WIDE_K; ++k) {
+                        const int sh = ((TD_WIDE_CPG * k) & 31) + c;           // column CPG k + c: its mask word and bit
+                        bool a, fresh;
+                        if (k < TD_WIDE_KL || t_w1) {
+                            a = (ms[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u;
+                            fresh = FIRST || ((ns[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u);
+                        } else { a = t_in; fresh = FIRST; }
+                        act[u] |= (a ? 1u : 0u) << k;
+                        rd[u] |= ((a && !fresh) ? 1u : 0u) << k;
+                    }
+                }
+                const float *eg = v.e + (gb + q) * TD_LD + tid * 4;
+#pragma unroll
+                for (int k = 0; k < TD_WIDE_K; ++k) {
+                    ev[u][k] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+                    if ((rd[u] >> k) & 1u) ev[u][k] = __builtin_nontemporal_load(reinterpret_cast<const td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GPI; ++u) {
+                const int q = q0 + u;
+                if (q >= m) break;
+                const uint32_t *rw = reinterpret_cast<const uint32_t *>(&fs[q][TD_F_ROW]);
+                const uint32_t r0 = rw[base], r1 = rw[base + 1], r2 = rw[base + 2], r3 = rw[base + 3];
+                // the positions where this thread's thermometer level is on (level 3: count >= 4, its value comes from the count)
+                const uint32_t tw = level == 0 ? (r0 | r1 | r2 | r3) : level == 1 ? (r1 | r2 | r3) : level == 2 ? ((r0 & r1) | r2 | r3) : (r2 | r3);
+                const float4 db = *reinterpret_cast<const float4 *>(&fs[q][TD_F_DB1 + n0]);
+                const float cf = cs[q];
+                float *eg = v.e + (gb + q) * TD_LD + tid * 4;
+#pragma unroll
+                for (int k = 0; k < TD_WIDE_K; ++k) {
+                    if (!((act[u] >> k) & 1u)) continue;
+                    td_f32x4 x = ev[u][k];
+                    bool wr;
+                    if (k < TD_WIDE_KL) {
+                        const int pos = pos0 + (TD_WIDE_CPG / 8) * k;
+                        float xj = (float)((tw >> pos) & 1u);
+                        if (level == 3) {
+                            const int cnt = (int)(((r0 >> pos) & 1u) | (((r1 >> pos) & 1u) << 1) | (((r2 >> pos) & 1u) << 2) | (((r3 >> pos) & 1u) << 3));
+                            xj = cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f;
+                        }
+                        x.x = fmaf(emul, x.x, (db.x * xj) * ginv);
+                        x.y = fmaf(emul, x.y, (db.y * xj) * ginv);
+                        x.z = fmaf(emul, x.z, (db.z * xj) * ginv);
+                        x.w = fmaf(emul, x.w, (db.w * xj) * ginv);
+                        wr = xj != 0.0f;
+                    } else {
+                        const float xj = t_w1 ? td_feature_value(rw, 192 + c) : 1.0f;
+                        x.x = fmaf(emul, x.x, (fs[q][ia[0]] * (t_w1 ? xj : xfix[0])) * ginv);
+                        x.y = fmaf(emul, x.y, (fs[q][ia[1]] * (t_w1 ? xj : xfix[1])) * ginv);
+                        x.z = fmaf(emul, x.z, (fs[q][ia[2]] * (t_w1 ? xj : xfix[2])) * ginv);
+                        x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (t_w1 ? xj : xfix[3])) * ginv);
+                        wr = !t_w1 || xj != 0.0f;
+                    }
+                    if (full || wr || !((rd[u] >> k) & 1u))
+                        __builtin_nontemporal_store(x, reinterpret_cast<td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)));
+                    acc[k].x = fmaf(cf, x.x, acc[k].x);
+                    acc[k].y = fmaf(cf, x.y, acc[k].y);
+                    acc[k].z = fmaf(cf, x.z, acc[k].z);
+                    acc[k].w = fmaf(cf, x.w, acc[k].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TD_WIDE_K; ++k)
+        if (k < TD_WIDE_KL || t_in)
+            *reinterpret_cast<td_f32x4 *>(v.partial + (long long)blockIdx.x * TD_LD + (k * TD_WIDE_THREADS + tid) * 4) = acc[k];
 }
 
 // block 256 = 64 parameters x 4 group lanes.  upd (optional) receives the summed update; apply adds it to theta

@@ -1589,6 +1589,7 @@ struct bgamd_td {
     bool has_weights = false, begun = false;
     int n_cu = 256;
     long long mfma_min = 3072;             // running games from which the forward pass goes to the matrix pipe (BGAMD_TD_MFMA_MIN)
+    long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
     uint64_t updates = 0;
@@ -1662,6 +1663,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
         td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 3072;
     }
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
+    if (getenv("BGAMD_TD_WIDE_MIN")) td->wide_min = atoll(getenv("BGAMD_TD_WIDE_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
     HIPCHK(hipMemset(v.wr_cols, 0, (size_t)max_games * 4));
@@ -1764,7 +1766,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     // games per group: >= 4, and at most TD_MAX_GROUPS groups
     long long ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
     if (ng < 4) ng = 4;
-    const int n_groups = (int)((n_active + ng - 1) / ng);
+    int n_groups = (int)((n_active + ng - 1) / ng);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (td->timing) {
         if (td->ev_used * 2 + 2 > td->ev.size()) {
@@ -1775,7 +1777,16 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         td->ev_used++;
         HIPCHK(hipEventRecord(e0, s));
     }
-    if (t == 0)
+    if (n_active >= td->wide_min) {
+        // large rounds: a workgroup per whole trace row and strided chunks of games (bg_learner.h)
+        n_groups = (int)((n_active + TD_CHUNK - 1) / TD_CHUNK);
+        if (n_groups > td->n_cu * BG_TD_WIDE_BPC) n_groups = td->n_cu * BG_TD_WIDE_BPC;
+        if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
+        if (t == 0)
+            hipLaunchKernelGGL(td_trace_wide_kernel<true>, dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);
+        else
+            hipLaunchKernelGGL(td_trace_wide_kernel<false>, dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
+    } else if (t == 0)
         hipLaunchKernelGGL(td_trace_kernel<true>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
                            (int)ng, emul, ginv, cmul, 1);
     else

@@ -21,7 +21,7 @@ for n in [int(x) for x in (sys.argv[1:] or ["512", "4096", "16384"])]:
     moved = ((cols + wcols) * 128 + 2 * gs * 257) * 4   # bytes read + written: active / written W1 columns + the dense b1 | W2 | b2 tail
     print(f"n={n} T={rows.shape[0]} updates={cnt} device replay {dt*1e3:.1f} ms -> {cnt/dt/1e6:.2f} M updates/s | trace kernel {ms:.1f} ms "
           f"({nl} launches): {cols/max(gs,1):.1f} of 198 W1 columns read, {wcols/max(gs,1):.1f} written per update, {moved/ms/1e6:.0f} GB/s moved "
-          f"(dense-equivalent {gs*204808/ms/1e6:.0f} GB/s)", flush=True)
+          f"(dense-equivalent {gs*204808/ms/1e6:.0f} GB/s); sum|theta| {float(L.theta.double().abs().sum()):.9g}", flush=True)
     if n <= 4096:
         X = env.encode_rows(rows)
         Lt = TDLambdaLearner(w, device="cuda", alpha=0.1, lam=0.9)
