@@ -458,7 +458,8 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
             ev[q] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
             if ((rd >> q) & 1u) {
                 const td_f32x4 *ep = reinterpret_cast<const td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
-                ev[q] = __builtin_nontemporal_load(ep);
+                                ev[q] = *ep;                                  // default cache policy: this kernel serves the rounds whose active trace
+                                                              // columns fit the Infinity Cache (< 8 192 running games; +3-4 % over nt)
             }
         }
 
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
                 x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (is_w1 ? xj : xfix[3])) * ginv);
                 if (full || !is_w1 || xj != 0.0f || !((rd >> q) & 1u)) {      // (not read = activated at this step: written whatever x_j is)
                     td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(v.e + (gb + q) * TD_LD + p0);
-                    __builtin_nontemporal_store(x, ep);
+                                        *ep = x;
                 }
                 const float cf = cs[q];
                 acc.x = fmaf(cf, x.x, acc.x);
