@@ -76,12 +76,14 @@ SYMBOLS = [
     ("bgamd_td_set_weights", C.c_int, [_P, _P, _P]),
     ("bgamd_td_get_weights", C.c_int, [_P, _P, _P]),
     ("bgamd_td_begin", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P]),
+    ("bgamd_td_begin_stream", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P, _P, _P]),
     ("bgamd_td_step", C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, C.c_float, _P, _P]),
     ("bgamd_td_apply", C.c_int, [_P, _P, _P]),
     ("bgamd_td_replay", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_double, C.c_float, _P]),
     ("bgamd_td_stats", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("bgamd_td_active_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("bgamd_td_written_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("bgamd_td_slots", C.c_int, [_P, _P]),
     ("bgamd_td_time", C.c_int, [_P, C.c_int]),
     ("bgamd_td_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]

@@ -18,6 +18,28 @@ import torch
 import torch.distributed as dist
 
 
+def stream_schedule(lengths, slots: int):
+    """The streamed replay's schedule: games (lanes with length > 0) are dealt to `slots` slots longest first in a snake (so
+    the slots' total lengths differ by about one game) and every slot plays its share in a fixed pseudo-random order.
+    -> (queue int32 [games] lanes in slot-major play order, qoff int32 [k + 1], n_steps = the longest slot total, k)."""
+    lengths = torch.as_tensor(lengths).to(torch.int32)
+    dev = lengths.device
+    sl, order = torch.sort(lengths, descending=True, stable=True)
+    n_games = int((sl > 0).sum().item())
+    order, sl = order[:n_games], sl[:n_games]
+    k = max(1, min(int(slots), n_games))
+    r = torch.arange(n_games, device=dev)
+    rnd, col = r // k, r % k
+    slot = torch.where(rnd % 2 == 0, col, k - 1 - col)
+    key = (order.to(torch.int64) * 2654435761 + 0x9E3779B9) % 4294967296
+    perm = torch.argsort(slot * 4294967296 + key)
+    queue = order[perm].to(torch.int32).contiguous()
+    qoff = torch.zeros(k + 1, dtype=torch.int32, device=dev)
+    qoff[1:] = torch.cumsum(torch.bincount(slot, minlength=k), 0).to(torch.int32)
+    tot = torch.zeros(k, dtype=torch.int64, device=dev).scatter_add_(0, slot, sl.to(torch.int64))
+    return queue, qoff, (int(tot.max().item()) if n_games else 0), (k if n_games else 0)
+
+
 class TDLambdaLearner:
     def __init__(self, weights_flat, device="cpu", alpha: float = 0.1, lam: float = 0.7, dtype=torch.float32):
         w = torch.as_tensor(weights_flat, dtype=dtype).flatten().to(device)
@@ -98,6 +120,53 @@ class TDLambdaLearner:
             cnt += active.sum()                                     # no host sync inside the loop
         return float(sq.item()), int(cnt.item())
 
+    def replay_stream(self, X, lengths, p1_won, slots: int, batch_scale: float = 1.0):
+        """The streamed replay (DeviceTDLambdaLearner.replay_rows(slots=k), bgamd_td_begin_stream) as a host closed form:
+        slot i replays its queue of games one after another, every step sums the updates of the slots' current turns."""
+        T, G = X.shape[0], X.shape[1]
+        dev, dt = self.theta.device, self.theta.dtype
+        lengths = torch.as_tensor(lengths, device=dev).long()
+        z_all = torch.as_tensor(p1_won, device=dev).to(dt)
+        queue, qoff, n_steps, k = stream_schedule(lengths, slots)
+        queue, qoff = queue.cpu().tolist(), qoff.cpu().tolist()
+        lens = lengths.cpu().tolist()
+        game = torch.full((n_steps, k), -1, dtype=torch.long)       # the game a slot replays at a step, and that game's own step
+        tl = torch.zeros((n_steps, k), dtype=torch.long)
+        for i in range(k):
+            s0 = 0
+            for q in range(qoff[i], qoff[i + 1]):
+                n = lens[queue[q]]
+                game[s0:s0 + n, i] = queue[q]
+                tl[s0:s0 + n, i] = torch.arange(n)
+                s0 += n
+        game, tl = game.to(dev), tl.to(dev)
+        e = torch.zeros((k, 25601), dtype=dt, device=dev)
+        eW1, eb1, eW2, eb2 = self._split(e)
+        sq, cnt = 0.0, 0
+        for s in range(n_steps):
+            gm, t = game[s], tl[s]
+            active = gm >= 0
+            gi = gm.clamp(min=0)
+            e[t == 0] = 0                                            # a slot's trace restarts with each game (train.py:133)
+            terminal = active & (lengths[gi] == t + 1)
+            W1, b1, W2, b2 = self._split(self.theta)
+            x = X[t.clamp(max=T - 1), gi].to(dt) * active.to(dt)[:, None]
+            v, h = self.values(x)
+            v_next, _ = self.values(X[(t + 1).clamp(max=T - 1), gi].to(dt))
+            delta = torch.where(terminal, z_all[gi] - v, v_next - v) * active.to(dt)
+            g = v * (1 - v) * active.to(dt)
+            db1 = (g[:, None] * W2[None, :]) * h * (1 - h)
+            lam = self.lambda_decay
+            eb2.mul_(lam).add_(g[:, None])
+            eW2.mul_(lam).addcmul_(g[:, None], h)
+            eb1.mul_(lam).add_(db1)
+            eW1.baddbmm_(db1[:, :, None], x[:, None, :], beta=lam, alpha=1.0)
+            coef = (self.learning_rate * batch_scale * delta.double()).to(dt)
+            self.theta.add_(coef @ e)
+            sq += float((delta.double() ** 2).sum().item())
+            cnt += int(active.sum().item())
+        return sq, cnt
+
     def state_dict(self):
         W1, b1, W2, b2 = TDLambdaLearner._split(self.theta.detach().cpu())
         return {"fc1.weight": W1.clone(), "fc1.bias": b1.clone(), "fc2.weight": W2.reshape(1, 128).clone(),
@@ -177,7 +246,7 @@ class DeviceTDLambdaLearner:
         return ms.value, n.value, gs.value
 
     def replay_rows(self, rows, lengths, p1_won, group=None, batch_scale: float = 1.0, split_apply: bool = False,
-                    sub_round: int = 0):
+                    sub_round: int = 0, slots: int = 0):
         """rows: int32 [T, n, 8] trajectory log (VecGame.record_trajectory / play_round), lengths: int [n] logged
         turns per lane (0 = do not replay), p1_won: bool [n].  Returns (Σ δ², number of (game, step) updates).
         split_apply: take the step / all-reduce / apply route of the distributed replay even on one rank.
@@ -185,7 +254,12 @@ class DeviceTDLambdaLearner:
         sub-round from the weights the one before left (the reference applies a round's games one after another,
         train.py:536-547; k = 1 is exactly that, k = games is one summed update per step).  The same trace traffic
         whatever k is; sub-rounds take every ceil(games / k)-th game of the length-sorted order, so each has the round's
-        mix of game lengths."""
+        mix of game lengths.
+        slots = k > 0: the STREAMED replay -- k slots replay the round's games one after another (a slot starts its next
+        game the step after its last one ended), so every training step sums the updates of k games at different plies and
+        the round takes ~(turns of the round) / k steps with all k slots busy, instead of ceil(games / k) sub-rounds of
+        (longest game) steps that mostly run nearly empty.  Games are dealt to the slots longest first in a snake (equal
+        slot totals), each slot plays its share in a fixed pseudo-random order."""
         rows = rows.contiguous()
         T, n = int(rows.shape[0]), int(rows.shape[1])
         lengths = torch.as_tensor(lengths, device=self.device).to(torch.int32).contiguous()
@@ -195,6 +269,9 @@ class DeviceTDLambdaLearner:
         sl, order = torch.sort(lengths, descending=True, stable=True)
         n_games = int((sl > 0).sum().item())
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if slots and slots > 0:
+            return self._replay_stream(rows, T, n, lengths, won, order[:n_games], sl[:n_games], int(slots), group, distributed,
+                                       batch_scale, split_apply)
         n_sub = 1
         if sub_round and sub_round > 0:
             n_sub = max(1, -(-n_games // int(sub_round)))
@@ -210,6 +287,37 @@ class DeviceTDLambdaLearner:
             sq_tot += sq
             cnt_tot += cnt
         return sq_tot, cnt_tot
+
+    def _replay_stream(self, rows, T, n, lengths, won, order, sl, slots, group, distributed, batch_scale, split_apply):
+        """Streamed replay (bgamd_td_begin_stream): order = lanes by decreasing length sl."""
+        C, lib, chk = self._C, self._lib, self._capi.check
+        n_games = int(order.numel())
+        queue, qoff, n_steps, k = stream_schedule(lengths, min(slots, self.max_games))
+        self._keep = (rows, lengths, won, queue, qoff)
+        chk(lib.bgamd_td_begin_stream(self._h, self._p(rows), T, n, self._p(queue), self._p(qoff), k,
+                                      self._p(lengths), self._p(won), self._s()), "td_begin_stream")
+        alpha = float(self.learning_rate) * float(batch_scale)
+        lam = float(self.lambda_decay)
+        if not distributed and not split_apply:
+            arr = (C.c_int64 * max(n_steps, 1))(*([k] * n_steps))
+            chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
+        else:
+            ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            if distributed:
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)  # every rank issues the same collectives
+            upd = torch.zeros(25601, dtype=torch.float32, device=self.device)
+            for t in range(int(ns.item())):
+                if n_games:
+                    chk(lib.bgamd_td_step(self._h, t, k, alpha, lam, self._p(upd), self._s()), "td_step")
+                else:
+                    upd.zero_()
+                if distributed:
+                    dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)  # the ONE collective per training step
+                chk(lib.bgamd_td_apply(self._h, self._p(upd), self._s()), "td_apply")
+        sq, cnt = C.c_double(), C.c_int64()
+        chk(lib.bgamd_td_stats(self._h, C.byref(sq), C.byref(cnt)), "td_stats")
+        self._keep = None
+        return float(sq.value), int(cnt.value)
 
     def _replay_order(self, rows, T, n, lengths, won, order, sl, group, distributed, batch_scale, split_apply):
         """Lock-step replay of the games order[...] (lanes, by decreasing length sl)."""

@@ -799,8 +799,8 @@ struct TrajRowsFetch {
     const uint4 *rows; const int4 *gmeta; long long t, n_lanes, T;
     __device__ __forceinline__ bool get(long long R, uint4 &u0, uint4 &u1) const
     {
-        const int4 gm = gmeta[R >> 1];
-        const long long tt = t + (R & 1);
+        const int4 gm = gmeta[R >> 1];                            // (lane, length, p1_won, the step the game started at)
+        const long long tt = t - gm.w + (R & 1);
         if (tt >= gm.y || tt >= T) return false;
         const uint4 *src = rows + (tt * n_lanes + gm.x) * 2;
         u0 = src[0]; u1 = src[1];

@@ -73,7 +73,12 @@ struct TdView {
     const int32_t *order;                // [n_games] lane index, by decreasing length
     const int32_t *length;               // [n_lanes]
     const uint8_t *p1_won;               // [n_lanes]
-    int4 *gmeta;                         // [max_games] (lane, length, p1_won, 0) by order position: one load, no chain
+    int4 *gmeta;                         // [max_games] (lane, length, p1_won, start step) of the game in slot i: one load, no chain
+    // streamed replay (bgamd_td_begin_stream): slot i plays the games queue[qoff[i] .. qoff[i + 1]) one after another; qcur[i] = the
+    // next one.  Lock-step replay: one game per slot, all starting at step 0 (queue == nullptr).
+    const int32_t *queue, *qoff;
+    int32_t *qcur;
+    unsigned int *nupd;                  // [max_games] (game, step) updates of the slot since begin
     uint16_t *wl3;                       // fc1.weight as three bf16 planes in the MFMA layout of bg_eval.h (refreshed with every update)
     uint2 *lut;                          // count -> 4 bf16 features
     float *hid;                          // [2 * max_games][128] W1 x + b1 of (s_t, s_{t+1}) per running game, from the MFMA pass
@@ -137,10 +142,49 @@ __global__ void td_gather_kernel(TdView v)
     int len = v.length[lane];
     len = len < 0 ? 0 : (len > v.T ? (int)v.T : len);
     v.gmeta[i] = make_int4(lane, len, v.p1_won[lane] ? 1 : 0, 0);
+    v.nupd[i] = 0u;
     v.sq[i] = 0.0;
     v.act_cols[i] = 0u;
     v.wr_cols[i] = 0u;
 }
+
+// Slot i takes the next game of its queue that has any turns (streamed replay), starting at step `start`, or falls empty
+// (length 0: a lock-step replay, or the queue is used up).
+__device__ __forceinline__ void td_advance_slot(const TdView &v, long long i, int start)
+{
+    int lane = 0, len = 0, won = 0;
+    if (v.queue) {
+        int c = v.qcur[i];
+        const int end = v.qoff[i + 1];
+        while (c < end && len == 0) {
+            lane = v.queue[c++];
+            lane = lane < 0 ? 0 : (lane >= v.n_lanes ? (int)v.n_lanes - 1 : lane);
+            len = v.length[lane];
+            len = len < 0 ? 0 : (len > v.T ? (int)v.T : len);
+            won = v.p1_won[lane] ? 1 : 0;
+        }
+        v.qcur[i] = c;
+    }
+    int4 gm;
+    gm.x = len ? lane : 0; gm.y = len; gm.z = len ? won : 0; gm.w = start;
+    v.gmeta[i] = gm;
+}
+
+__global__ void td_gather_stream_kernel(TdView v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n_games) return;                          // n_games = slots here
+    v.qcur[i] = v.qoff[i];
+    td_advance_slot(v, i, 0);
+    v.nupd[i] = 0u;
+    v.sq[i] = 0.0;
+    v.act_cols[i] = 0u;
+    v.wr_cols[i] = 0u;
+}
+
+// mask word 7 of a slot carries two flags for the trace pass: amask: the slot holds a running game; anew: it is the game's first step
+// (nothing of the slot's trace is read: the previous game's is dead)
+constexpr int TD_FLAG_WORD = 7;
 
 // TD_GB games x {s_t, s_{t+1}} per workgroup of 128 threads (2 for small rounds: a shorter FMA chain per thread and
 // more workgroups; 4 for large ones: half the W1 traffic)
@@ -152,6 +196,7 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
 {
     constexpr int NR = 2 * TD_GB;                         // rows: [s][game]
     __shared__ unsigned int s_colsg[TD_GB], s_wrg[TD_GB];
+    __shared__ int adv[TD_GB];
     __shared__ __attribute__((aligned(16))) float xs[PRE ? 1 : N_IN][NR];
     __shared__ uint32_t srow[TD_GB][8];                   // the 32-byte row of s_t of every game of the block
     __shared__ uint32_t smask[TD_GB][TD_MASK_WORDS];
@@ -177,14 +222,16 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const long long i = i0 + g;
         bool live = i < n_active;
         int lane = 0;
+        long long tl = 0;                                 // the game's own step
         if (live && (!PRE || (s == 0 && c == 0))) {
             const int4 gm = v.gmeta[i];
             lane = gm.x;
-            live = (t + s) < gm.y && (t + s) < v.T;       // s_{t+1} does not exist on the terminal step
+            tl = t - gm.w;
+            live = (tl + s) < gm.y && (tl + s) < v.T;     // s_{t+1} does not exist on the terminal step
         } else if (PRE) live = false;                     // the matrix-pipe pass has decoded the rows: only s_t is needed here, once
         uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
-            const uint4 *src = v.rows + ((t + s) * v.n_lanes + lane) * 2;
+            const uint4 *src = v.rows + ((tl + s) * v.n_lanes + lane) * 2;
             const uint4 u0 = src[0], u1 = src[1];
             p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
         }
@@ -229,7 +276,7 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         }
     }
     const float w2 = v.theta[TD_OFF_W2 + n];
-    if (tid < TD_GB) { s_colsg[tid] = 0; s_wrg[tid] = 0; }
+    if (tid < TD_GB) { s_colsg[tid] = 0; s_wrg[tid] = 0; adv[tid] = 0; }
     __syncthreads();
     // ---- ever-active feature masks of the games: thread = (game, board point | tail) ORs its 8 (6) "x_j != 0" bits into the
     //      game's mask words; the trace pass touches only these columns ----
@@ -245,13 +292,16 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
         const long long i = i0 + g;
         if (i < n_active) {
+            const int4 gm = v.gmeta[i];
+            const bool run = (t - gm.w) < gm.y, first = t == gm.w;
             uint32_t now = smask[g][wd];
             const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);     // 198 = 6 * 32 + 6
             const uint32_t nz = now & valid;
             if (v.dense) now = valid;
-            const uint32_t old = t == 0 ? 0u : v.amask[i * TD_MASK_WORDS + wd];
-            v.amask[i * TD_MASK_WORDS + wd] = old | now;
-            v.anew[i * TD_MASK_WORDS + wd] = now & ~old;
+            if (!run) now = 0u;
+            const uint32_t old = (first || !run || wd == TD_FLAG_WORD) ? 0u : v.amask[i * TD_MASK_WORDS + wd];
+            v.amask[i * TD_MASK_WORDS + wd] = wd == TD_FLAG_WORD ? (run ? 1u : 0u) : (old | now);
+            v.anew[i * TD_MASK_WORDS + wd] = wd == TD_FLAG_WORD ? (first ? 1u : 0u) : (now & ~old);
             atomicAdd(&s_colsg[g], (unsigned int)__popc(old | now));
             atomicAdd(&s_wrg[g], (unsigned int)__popc(v.full_step ? (old | now) : (nz | (now & ~old))));
         }
@@ -299,12 +349,17 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         float g = 0.0f;
         if (i < n_active) {
             const int4 gm = v.gmeta[i];
-            const float val = outs[tid], vnext = outs[TD_GB + tid];
-            const float z = gm.z ? 1.0f : 0.0f;
-            const float delta = (t + 1 >= gm.y) ? z - val : vnext - val;   // lengths never exceed the log (host check)
-            g = val * (1.0f - val);
-            v.coef[i] = (float)(alpha * (double)delta);
-            v.sq[i] += (double)delta * (double)delta;
+            const long long tl = t - gm.w;
+            if (tl < gm.y) {
+                const float val = outs[tid], vnext = outs[TD_GB + tid];
+                const float z = gm.z ? 1.0f : 0.0f;
+                const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;   // lengths never exceed the log (host check)
+                g = val * (1.0f - val);
+                v.coef[i] = (float)(alpha * (double)delta);
+                v.sq[i] += (double)delta * (double)delta;
+                v.nupd[i] += 1u;
+                if (tl + 1 >= gm.y) adv[tid] = 1;                          // the slot takes its next game (below, after the last read of gmeta)
+            } else v.coef[i] = 0.0f;
         }
         gs[tid] = g;
     }
@@ -324,6 +379,7 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
     if (tid < TD_GB && i0 + tid < n_active) {                                      // (the barriers above ordered the LDS adds)
         v.act_cols[i0 + tid] += s_colsg[tid];
         v.wr_cols[i0 + tid] += s_wrg[tid];
+        if (adv[tid]) td_advance_slot(v, i0 + tid, (int)(t + 1));
     }
 }
 
@@ -338,12 +394,18 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_active) return;                                 // whole waves leave: no barrier below
     const int4 gm = v.gmeta[i];
+    const long long tl = t - gm.w;                             // the game's own step
+    if (tl >= gm.y) {                                          // a slot whose queue is used up (streamed replay): nothing to add
+        if (lane < TD_MASK_WORDS) { v.amask[i * TD_MASK_WORDS + lane] = 0u; v.anew[i * TD_MASK_WORDS + lane] = 0u; }
+        if (lane == 9) v.coef[i] = 0.0f;
+        return;
+    }
     const float *hp = v.hid + 2 * i * N_HID;
     const float a0 = hp[lane], a1 = hp[lane + 64], c0 = hp[N_HID + lane], c1 = hp[N_HID + lane + 64];     // s_t | s_{t+1}
     const float w20 = v.theta[TD_OFF_W2 + lane], w21 = v.theta[TD_OFF_W2 + lane + 64], b2 = v.theta[TD_OFF_B2];
     uint32_t old = 0;
-    if (t != 0 && lane < TD_MASK_WORDS) old = v.amask[i * TD_MASK_WORDS + lane];
-    const uint4 *src = v.rows + (t * v.n_lanes + gm.x) * 2;    // s_t exists for every running game
+    if (tl != 0 && lane < TD_FLAG_WORD) old = v.amask[i * TD_MASK_WORDS + lane];
+    const uint4 *src = v.rows + (tl * v.n_lanes + gm.x) * 2;   // s_t exists for every running game
     const uint4 u0 = src[0], u1 = src[1];
     const uint32_t row[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
     const float h0 = td_sigmoid(a0), h1 = td_sigmoid(a1), k0 = td_sigmoid(c0), k1 = td_sigmoid(c1);
@@ -352,7 +414,7 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     for (int m = 32; m >= 1; m >>= 1) { sv += __shfl_xor(sv, m, 64); sn += __shfl_xor(sn, m, 64); }
     const float val = td_sigmoid(sv + b2), vnext = td_sigmoid(sn + b2);
     const float z = gm.z ? 1.0f : 0.0f;
-    const float delta = (t + 1 >= gm.y) ? z - val : vnext - val;
+    const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
     const float g = val * (1.0f - val);
     float *f = v.fac + i * TD_FLD;
     f[TD_F_DB1 + lane] = (g * w20) * (1.0f - h0) * h0;
@@ -361,7 +423,7 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     f[TD_F_GH + lane + 64] = g * h1;
     if (lane < 8) f[TD_F_ROW + lane] = __uint_as_float(row[lane & 7]);
     if (lane == 8) f[TD_F_G] = g;
-    if (lane == 9) { v.coef[i] = (float)(alpha * (double)delta); v.sq[i] += (double)delta * (double)delta; }
+    if (lane == 9) { v.coef[i] = (float)(alpha * (double)delta); v.sq[i] += (double)delta * (double)delta; v.nupd[i] += 1u; }
     // ever-active feature mask: lane pt < 25 forms the 8 (6) "x_j != 0" bits of board point pt (the tail), a quad of lanes
     // is one 32-bit word
     uint32_t bits = lane < 25 ? td_nonzero_bits(row, lane) << (8 * (lane & 3)) : 0u;
@@ -373,14 +435,17 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
         const uint32_t valid = lane < 6 ? 0xFFFFFFFFu : (lane == 6 ? 0x3Fu : 0u);
         const uint32_t nz = now & valid;
         now = v.dense ? valid : nz;
-        v.amask[i * TD_MASK_WORDS + lane] = old | now;
-        v.anew[i * TD_MASK_WORDS + lane] = now & ~old;
+        v.amask[i * TD_MASK_WORDS + lane] = lane == TD_FLAG_WORD ? 1u : (old | now);
+        v.anew[i * TD_MASK_WORDS + lane] = lane == TD_FLAG_WORD ? (tl == 0 ? 1u : 0u) : (now & ~old);
         wr = (unsigned int)__popc(v.full_step ? (old | now) : (nz | (now & ~old)));
     }
     unsigned int cols = lane < TD_MASK_WORDS ? (unsigned int)__popc(old | now) : 0u;
 #pragma unroll
     for (int m = 4; m >= 1; m >>= 1) { cols += __shfl_xor(cols, m, 64); wr += __shfl_xor(wr, m, 64); }
-    if (lane == 0) { v.act_cols[i] += cols; v.wr_cols[i] += wr; }
+    if (lane == 0) {
+        v.act_cols[i] += cols; v.wr_cols[i] += wr;
+        if (tl + 1 >= gm.y) td_advance_slot(v, i, (int)(t + 1));    // the slot takes its next game (streamed replay) or falls empty
+    }
 }
 
 // grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace (internal order); `ng` games per group.
@@ -446,8 +511,8 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
 #pragma unroll
             for (int q = 0; q < TD_CHUNK; ++q)
                 if (q < m) {
-                    const bool a = !is_w1 || (ms[q][mword] & mbit);
-                    const bool fresh = FIRST || (is_w1 && (ns[q][mword] & mbit));
+                    const bool a = is_w1 ? (ms[q][mword] & mbit) != 0u : (ms[q][TD_FLAG_WORD] & 1u) != 0u;     // b1 | W2 | b2: a running game
+                    const bool fresh = FIRST || (is_w1 ? (ns[q][mword] & mbit) != 0u : (ns[q][TD_FLAG_WORD] & 1u) != 0u);
                     act |= (a ? 1u : 0u) << q;
                     rd |= ((a && !fresh) ? 1u : 0u) << q;
                 }
@@ -571,7 +636,7 @@ __global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide
                         if (k < TD_WIDE_KL || t_w1) {
                             a = (ms[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u;
                             fresh = FIRST || ((ns[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u);
-                        } else { a = t_in; fresh = FIRST; }
+                        } else { a = t_in && (ms[q][TD_FLAG_WORD] & 1u); fresh = FIRST || (ns[q][TD_FLAG_WORD] & 1u); }
                         act[u] |= (a ? 1u : 0u) << k;
                         rd[u] |= ((a && !fresh) ? 1u : 0u) << k;
                     }

@@ -1592,7 +1592,7 @@ struct bgamd_td {
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
-    uint64_t updates = 0;
+    bool stream_mode = false;              // bgamd_td_begin_stream: slots take game after game, steps are not bounded by the log length
     bool timing = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -1647,6 +1647,8 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.anew, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.act_cols, (size_t)max_games * 4);
     TDALLOC(v.wr_cols, (size_t)max_games * 4);
+    TDALLOC(v.nupd, (size_t)max_games * 4);
+    TDALLOC(v.qcur, (size_t)max_games * 4);
     TDALLOC(v.wl3, 3 * EVAL16_W_BYTES);
     TDALLOC(v.lut, EVAL16_LUT_BYTES);
     TDALLOC(v.hid, (size_t)max_games * 2 * N_HID * 4);
@@ -1679,7 +1681,7 @@ int bgamd_td_destroy(bgamd_td *td)
     hipSetDevice(td->device);
     hipDeviceSynchronize();
     TdView &v = td->v;
-    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wr_cols, v.wl3, v.lut, v.hid};
+    void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wr_cols, v.nupd, v.qcur, v.wl3, v.lut, v.hid};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
     delete td;
@@ -1718,18 +1720,43 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
     v.length = d_length;
     v.p1_won = d_p1_won;
     v.T = T; v.n_lanes = n_lanes; v.n_games = n_games;
+    v.queue = nullptr; v.qoff = nullptr;
     if (n_games > 0) {
         hipLaunchKernelGGL(td_gather_kernel, grid1(n_games, 256), dim3(256), 0, (hipStream_t)stream, v);
         HIPCHK(hipGetLastError());
     }
-    td->updates = 0;
     td->begun = true;
+    td->stream_mode = false;
+    return BGAMD_OK;
+}
+
+int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
+                          const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
+{
+    if (!td || !d_rows || !d_queue || !d_queue_offsets || !d_length || !d_p1_won || T <= 0 || n_lanes <= 0 || n_slots < 0 ||
+        n_slots > td->max_games)
+        return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    TdView &v = td->v;
+    v.rows = (const uint4 *)d_rows;
+    v.order = nullptr;
+    v.length = d_length;
+    v.p1_won = d_p1_won;
+    v.T = T; v.n_lanes = n_lanes; v.n_games = n_slots;
+    v.queue = d_queue; v.qoff = d_queue_offsets;
+    if (n_slots > 0) {
+        hipLaunchKernelGGL(td_gather_stream_kernel, grid1(n_slots, 256), dim3(256), 0, (hipStream_t)stream, v);
+        HIPCHK(hipGetLastError());
+    }
+    td->begun = true;
+    td->stream_mode = true;
     return BGAMD_OK;
 }
 
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream)
 {
-    if (!td || !td->begun || t < 0 || t >= td->v.T || n_active < 0 || n_active > td->v.n_games) return BGAMD_E_INVALID;
+    if (!td || !td->begun || t < 0 || (t >= td->v.T && !td->stream_mode) || t > 0x7FFFFFF0ll || n_active < 0 || n_active > td->v.n_games)
+        return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
     if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
     hipStream_t s = (hipStream_t)stream;
@@ -1799,7 +1826,6 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     }
     hipLaunchKernelGGL(td_reduce_kernel, grid1(TD_P, 64), dim3(256), 0, s, v, n_groups, d_update, d_update ? 0 : 1);
     HIPCHK(hipGetLastError());
-    td->updates += (uint64_t)n_active;
     return BGAMD_OK;
 }
 
@@ -1815,7 +1841,7 @@ int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream)
 
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream)
 {
-    if (!td || !h_n_active || n_steps < 0 || (td->begun && n_steps > td->v.T)) return BGAMD_E_INVALID;
+    if (!td || !h_n_active || n_steps < 0 || (td->begun && !td->stream_mode && n_steps > td->v.T)) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
     for (int64_t t = 0; t < n_steps; ++t) {
         if (h_n_active[t] == 0) continue;
@@ -1837,7 +1863,13 @@ int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
         for (double x : sq) acc += x;
         *h_sq_sum = acc;
     }
-    if (h_updates) *h_updates = (int64_t)td->updates;
+    if (h_updates) {
+        std::vector<unsigned int> c((size_t)td->v.n_games);
+        if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.nupd, c.size() * 4, hipMemcpyDeviceToHost));
+        int64_t tot = 0;
+        for (unsigned int x : c) tot += x;
+        *h_updates = tot;
+    }
     return BGAMD_OK;
 }
 
@@ -1851,6 +1883,27 @@ int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns)
     uint64_t tot = 0;
     for (unsigned int x : c) tot += x;
     *h_columns = tot;
+    return BGAMD_OK;
+}
+
+int bgamd_td_slots(bgamd_td *td, int32_t *h_out)
+{
+    if (!td || !h_out) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t n = (size_t)td->v.n_games;
+    std::vector<int32_t> gm(4 * n), qc(n);
+    std::vector<unsigned int> nu(n);
+    if (n) {
+        HIPCHK(hipMemcpy(gm.data(), td->v.gmeta, n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(qc.data(), td->v.qcur, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nu.data(), td->v.nupd, n * 4, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) h_out[6 * i + k] = gm[4 * i + k];
+        h_out[6 * i + 4] = td->stream_mode ? qc[i] : -1;
+        h_out[6 * i + 5] = (int32_t)nu[i];
+    }
     return BGAMD_OK;
 }
 

@@ -259,6 +259,16 @@ int bgamd_td_set_weights(bgamd_td *td, const float *d_theta, void *stream);
 int bgamd_td_get_weights(bgamd_td *td, float *d_theta, void *stream);
 int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_order,
                    int64_t n_games, const int32_t *d_length, const uint8_t *d_p1_won, void *stream);
+/* Streamed replay of a round (replaces the loop over a round's games of train.py:536-547 for rounds far larger than the
+ * reference's): n_slots slots replay the round's games one after another -- slot i plays the games (lanes of the log)
+ * d_queue[d_queue_offsets[i] .. d_queue_offsets[i + 1]), a game's step 0 following the terminal step of the game before it in
+ * the next training step -- so every training step sums the TD(lambda) updates of n_slots games at DIFFERENT plies, and the
+ * round takes max_i (sum of slot i's game lengths) steps instead of (sub-rounds) x (longest game).  A slot's trace restarts
+ * with each game (train.py:133 reset_eligibility_traces).  Then bgamd_td_step(t, n_slots, ...) for t = 0, 1, ... (steps past a
+ * slot's last game add nothing for it); t is not bounded by T here.  One game per slot == bgamd_td_begin with that order. */
+int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
+                          const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won,
+                          void *stream);
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream);
 int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream);
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream);
@@ -272,6 +282,9 @@ int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns);
  * c is folded back in by an ordinary pass when it leaves [2^-40, 2^40].  BGAMD_TD_LAZY=0 at bgamd_td_create: every step is an
  * ordinary pass (written = active).  Synchronises. */
 int bgamd_td_written_columns(bgamd_td *td, uint64_t *h_columns);
+/* Diagnostics: the replay's slots (lock-step: one per game) -> int32 h_out[n][6] = (lane, length, p1_won, start step) of the game
+ * a slot holds (length 0: none), the slot's queue cursor (-1 in a lock-step replay), its (game, step) updates so far.  Synchronises. */
+int bgamd_td_slots(bgamd_td *td, int32_t *h_out);
 /* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1) */
 int bgamd_td_time(bgamd_td *td, int enable);
 int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps);

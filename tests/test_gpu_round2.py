@@ -506,6 +506,54 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     assert dt_pool < 0.01
 
 
+@pytest.mark.parametrize("variant", ["default", "matrix_pipe_and_wide"])
+def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
+    """bgamd_td_begin_stream: k slots replay the round's games one after another.  Against the float64 host closed form of the
+    same schedule (ragged lengths, lanes that are not replayed, a one-turn game), for 1, 7 and 64 slots, on the small-round
+    kernels and on the large-round ones (matrix-pipe forward pass + whole-row trace workgroups forced down to this size); a slot
+    per game equals the lock-step replay; the (game, step) count is the round's turns; deterministic run to run."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n = 160
+    env = bg.VecGame(n, seed=321)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    lengths = lengths.clone()
+    lengths[::9] = 0
+    lengths[5] = 1
+    turns = int(lengths.sum().item())
+    Xr = env.encode_rows(rows).cpu().double()
+    if variant != "default":
+        os.environ["BGAMD_TD_MFMA_MIN"] = "1"; os.environ["BGAMD_TD_WIDE_MIN"] = "1"
+    try:
+        mk = lambda: DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+        learners = [mk() for _ in range(3)]
+    finally:
+        os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None)
+    for slots in (1, 7, 64):
+        Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.8, dtype=torch.float64)
+        sq_c, cnt_c = Lc.replay_stream(Xr, lengths.cpu(), p1_won.cpu(), slots=slots, batch_scale=0.3)
+        out = []
+        for Ld in learners[:2]:
+            Ld.set_weights(weights)
+            sq_d, cnt_d = Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=slots)
+            out.append(_np(Ld.theta))
+            assert cnt_d == cnt_c == turns and abs(sq_d - sq_c) < 1e-3 * max(1.0, sq_c)
+        assert np.array_equal(out[0], out[1])
+        moved = np.abs(Lc.theta.numpy() - weights).max()
+        d = np.abs(out[0] - Lc.theta.numpy()).max()
+        print("%s, %d slots: weights moved by %.3g, device - host fp64 = %.3g" % (variant, slots, moved, d))
+        assert moved > 1e-3 and d < 2e-5 * max(1.0, moved), (slots, d, moved)
+        Ld = learners[2]                                        # the distributed route on one rank
+        Ld.set_weights(weights)
+        sq_s, cnt_s = Ld.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=slots, split_apply=True)
+        assert cnt_s == turns and np.array_equal(_np(Ld.theta), out[0])
+    a, b = learners[0], learners[1]
+    a.set_weights(weights); b.set_weights(weights)
+    a.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=n)          # a slot per game ...
+    b.replay_rows(rows, lengths, p1_won, batch_scale=0.3)                   # ... is the lock-step replay
+    assert np.abs(_np(a.theta) - _np(b.theta)).max() < 2e-6
+
+
 def test_lazily_scaled_traces_equal_the_ordinary_pass(bg, weights):
     """The stored trace is e / c with one scale c = Π λ per replay, so columns whose feature is zero at a step are read but
     not written.  BGAMD_TD_LAZY=0 runs e <- λ e + ∇ on every column at every step (round 1's arithmetic to the bit).  Same

@@ -78,3 +78,36 @@ def test_oracle_td_restatement_matches_reference_fixture_and_host_learner(golden
     sql, cntl = L.replay(torch.from_numpy(Xm).double(), lengths, [1, 0, 1, 0, 1], batch_scale=0.5)
     assert cntl == cnto == sum(lengths)
     assert np.abs(L.theta.numpy() - tho).max() < 1e-12 and abs(sql - sqo) < 1e-9
+
+
+def test_streamed_replay_host_closed_form(weights):
+    """The streamed schedule (slots take game after game): with one slot it IS the reference's order -- a round's games
+    replayed one after another, traces reset per game, every later game from the weights the earlier ones left
+    (train.py:536-547) -- and with a slot per game it is the lock-step replay."""
+    import torch
+    from backgammon_env.learner import TDLambdaLearner, stream_schedule
+    g = torch.Generator().manual_seed(3)
+    T, G = 12, 9
+    X = (torch.rand(T, G, 198, generator=g) > 0.85).double()
+    lengths = torch.tensor([5, 12, 0, 7, 1, 9, 3, 12, 4])
+    won = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0, 1], dtype=torch.bool)
+    queue, qoff, n_steps, k = stream_schedule(lengths, 1)
+    assert k == 1 and n_steps == int(lengths.sum()) and sorted(queue.tolist()) == [0, 1, 3, 4, 5, 6, 7, 8]
+    a = TDLambdaLearner(weights, alpha=0.1, lam=0.7, dtype=torch.float64)
+    sq_a, cnt_a = a.replay_stream(X, lengths, won, slots=1, batch_scale=0.5)
+    b = TDLambdaLearner(weights, alpha=0.1, lam=0.7, dtype=torch.float64)
+    sq_b = 0.0
+    for lane in queue.tolist():                                  # one game at a time, in the slot's order
+        s, _ = b.replay(X[:, lane:lane + 1], lengths[lane:lane + 1], won[lane:lane + 1], batch_scale=0.5)
+        sq_b += s
+    assert cnt_a == int(lengths.sum()) and abs(sq_a - sq_b) < 1e-12
+    assert (a.theta - b.theta).abs().max() < 1e-13 and (a.theta - torch.as_tensor(weights).double()).abs().max() > 1e-4
+    c = TDLambdaLearner(weights, alpha=0.1, lam=0.7, dtype=torch.float64)
+    c.replay_stream(X, lengths, won, slots=64, batch_scale=0.5)
+    d = TDLambdaLearner(weights, alpha=0.1, lam=0.7, dtype=torch.float64)
+    d.replay(X, lengths, won, batch_scale=0.5)
+    assert (c.theta - d.theta).abs().max() < 1e-13
+    # three slots: every game exactly once, slot totals balanced
+    queue, qoff, n_steps, k = stream_schedule(lengths, 3)
+    tot = [int(lengths[queue[qoff[i]:qoff[i + 1]].long()].sum()) for i in range(3)]
+    assert k == 3 and sorted(queue.tolist()) == [0, 1, 3, 4, 5, 6, 7, 8] and n_steps == max(tot) and max(tot) - min(tot) <= 12
