@@ -76,6 +76,7 @@ SYMBOLS = [
     ("bgamd_td_set_weights", C.c_int, [_P, _P, _P]),
     ("bgamd_td_get_weights", C.c_int, [_P, _P, _P]),
     ("bgamd_td_begin", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P]),
+    ("bgamd_td_stream_schedule", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("bgamd_td_begin_stream", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P, _P, _P]),
     ("bgamd_td_step", C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, C.c_float, _P, _P]),
     ("bgamd_td_apply", C.c_int, [_P, _P, _P]),

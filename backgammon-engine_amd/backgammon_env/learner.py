@@ -14,30 +14,38 @@ from the reference, which replays games one after another.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
 def stream_schedule(lengths, slots: int):
-    """The streamed replay's schedule: games (lanes with length > 0) are dealt to `slots` slots longest first in a snake (so
-    the slots' total lengths differ by about one game) and every slot plays its share in a fixed pseudo-random order.
+    """The streamed replay's schedule (the host restatement of bgamd_td_stream_schedule, include/bgamd.h: the two must agree,
+    tests/test_learner_cpu.py): games (lanes with length > 0) are dealt longest first (ties: the lower lane), each to the slot with the
+    fewest turns so far (ties: the lower slot), so the slots' totals end up within a short game of each other and the replay
+    takes max-total steps with every slot busy almost to the end; every slot plays its share in a fixed pseudo-random order.
     -> (queue int32 [games] lanes in slot-major play order, qoff int32 [k + 1], n_steps = the longest slot total, k)."""
-    lengths = torch.as_tensor(lengths).to(torch.int32)
+    import heapq
+    lengths = torch.as_tensor(lengths)
     dev = lengths.device
-    sl, order = torch.sort(lengths, descending=True, stable=True)
-    n_games = int((sl > 0).sum().item())
-    order, sl = order[:n_games], sl[:n_games]
-    k = max(1, min(int(slots), n_games))
-    r = torch.arange(n_games, device=dev)
-    rnd, col = r // k, r % k
-    slot = torch.where(rnd % 2 == 0, col, k - 1 - col)
-    key = (order.to(torch.int64) * 2654435761 + 0x9E3779B9) % 4294967296
-    perm = torch.argsort(slot * 4294967296 + key)
-    queue = order[perm].to(torch.int32).contiguous()
-    qoff = torch.zeros(k + 1, dtype=torch.int32, device=dev)
-    qoff[1:] = torch.cumsum(torch.bincount(slot, minlength=k), 0).to(torch.int32)
-    tot = torch.zeros(k, dtype=torch.int64, device=dev).scatter_add_(0, slot, sl.to(torch.int64))
-    return queue, qoff, (int(tot.max().item()) if n_games else 0), (k if n_games else 0)
+    ln = lengths.cpu().to(torch.int64).tolist()
+    games = sorted((l for l in range(len(ln)) if ln[l] > 0), key=lambda l: -ln[l])     # stable: ties keep the lower lane first
+    k = max(1, min(int(slots), len(games)))
+    heap = [(0, i) for i in range(k)]
+    share = [[] for _ in range(k)]
+    n_steps = 0
+    for g in games:
+        tot, i = heapq.heappop(heap)
+        share[i].append(g)
+        tot += ln[g]
+        n_steps = max(n_steps, tot)
+        heapq.heappush(heap, (tot, i))
+    queue, qoff = [], [0]
+    for sh in share:
+        queue += sorted(sh, key=lambda l: (l * 2654435761 + 0x9E3779B9) % 4294967296)
+        qoff.append(len(queue))
+    return (torch.tensor(queue, dtype=torch.int32, device=dev), torch.tensor(qoff, dtype=torch.int32, device=dev),
+            n_steps, (k if games else 0))
 
 
 class TDLambdaLearner:
@@ -292,7 +300,17 @@ class DeviceTDLambdaLearner:
         """Streamed replay (bgamd_td_begin_stream): order = lanes by decreasing length sl."""
         C, lib, chk = self._C, self._lib, self._capi.check
         n_games = int(order.numel())
-        queue, qoff, n_steps, k = stream_schedule(lengths, min(slots, self.max_games))
+        # the schedule comes from the library (host code: a copy of the lengths goes down, the two index arrays come up)
+        h_len = lengths.cpu().numpy().astype(np.int32, copy=False)
+        k = max(1, min(int(slots), self.max_games))
+        h_queue, h_qoff = np.zeros(max(n, 1), dtype=np.int32), np.zeros(k + 1, dtype=np.int32)
+        ng, nst = C.c_int64(), C.c_int64()
+        chk(lib.bgamd_td_stream_schedule(h_len.ctypes.data, n, k, h_queue.ctypes.data, h_qoff.ctypes.data, C.byref(ng), C.byref(nst)),
+            "td_stream_schedule")
+        k = min(k, int(ng.value))
+        n_steps = int(nst.value)
+        queue = torch.from_numpy(h_queue[:max(int(ng.value), 1)]).to(self.device)
+        qoff = torch.from_numpy(h_qoff[:k + 1]).to(self.device)
         self._keep = (rows, lengths, won, queue, qoff)
         chk(lib.bgamd_td_begin_stream(self._h, self._p(rows), T, n, self._p(queue), self._p(qoff), k,
                                       self._p(lengths), self._p(won), self._s()), "td_begin_stream")

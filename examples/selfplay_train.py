@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--eps", type=float, default=None, help="fixed exploration rate (overrides the linear decay)")
     ap.add_argument("--sub-round", type=int, default=0, help="replay the round in sub-rounds of this many games, weights "
                     "refreshed between them (0 = the whole round lock-step)")
+    ap.add_argument("--slots", type=int, default=0, help="streamed replay: this many slots replay the round's games one after another "
+                    "(every training step sums the updates of that many games at different plies; overrides --sub-round)")
     ap.add_argument("--scale-games", type=float, default=24.0, help="every game's update is scaled by min(1, this / games per "
                     "(sub-)round): 24 = the summed update of a reference-sized round (round_size = workers <= 24, train.py:307-312)")
     ap.add_argument("--arena", type=int, default=1024, help="lanes of the evaluation arena (2 games per lane, sides alternated)")
@@ -95,12 +97,12 @@ def main():
             d = env.dice().clone()
             assert first_dice is None or not torch.equal(d, first_dice), "two rounds rolled the same dice"
             first_dice = d
-        sub = a.sub_round if a.sub_round > 0 else a.games
+        sub = a.slots if a.slots > 0 else a.sub_round if a.sub_round > 0 else a.games
         scale = min(1.0, a.scale_games / (min(sub, a.games) * world))
         if a.host_learner:
             sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, group=group, batch_scale=scale)
         else:
-            sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale, sub_round=a.sub_round)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale, sub_round=a.sub_round, slots=a.slots)
         turns += cnt
         if r % 20 == 19 or r == a.rounds - 1:
             say(f"round {r + 1}: {(r + 1) * a.games * world} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "

@@ -266,6 +266,12 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
  * round takes max_i (sum of slot i's game lengths) steps instead of (sub-rounds) x (longest game).  A slot's trace restarts
  * with each game (train.py:133 reset_eligibility_traces).  Then bgamd_td_step(t, n_slots, ...) for t = 0, 1, ... (steps past a
  * slot's last game add nothing for it); t is not bounded by T here.  One game per slot == bgamd_td_begin with that order. */
+/* Host-only helper (no device needed): the schedule of a streamed replay.  h_length[n_lanes] = logged turns per lane (<= 0: not
+ * replayed).  Games are dealt longest first, each to the slot with the fewest turns so far, and every slot plays its share in a fixed
+ * pseudo-random order.  -> h_queue[games] lanes in slot-major play order, h_queue_offsets[n_slots + 1], the number of games and the
+ * number of training steps (= the largest slot total).  bgamd_td_begin_stream takes these two arrays (copied to the device). */
+int bgamd_td_stream_schedule(const int32_t *h_length, int64_t n_lanes, int64_t n_slots, int32_t *h_queue, int32_t *h_queue_offsets,
+                             int64_t *h_n_games, int64_t *h_n_steps);
 int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
                           const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won,
                           void *stream);

@@ -506,7 +506,7 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     assert dt_pool < 0.01
 
 
-@pytest.mark.parametrize("variant", ["default", "matrix_pipe_and_wide"])
+@pytest.mark.parametrize("variant", ["default", "matrix_pipe", "wide", "matrix_pipe_and_wide"])
 def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     """bgamd_td_begin_stream: k slots replay the round's games one after another.  Against the float64 host closed form of the
     same schedule (ragged lengths, lanes that are not replayed, a one-turn game), for 1, 7 and 64 slots, on the small-round
@@ -522,8 +522,10 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     lengths[5] = 1
     turns = int(lengths.sum().item())
     Xr = env.encode_rows(rows).cpu().double()
-    if variant != "default":
-        os.environ["BGAMD_TD_MFMA_MIN"] = "1"; os.environ["BGAMD_TD_WIDE_MIN"] = "1"
+    if "matrix_pipe" in variant:
+        os.environ["BGAMD_TD_MFMA_MIN"] = "1"
+    if "wide" in variant:
+        os.environ["BGAMD_TD_WIDE_MIN"] = "1"
     try:
         mk = lambda: DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
         learners = [mk() for _ in range(3)]
@@ -552,6 +554,33 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     a.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=n)          # a slot per game ...
     b.replay_rows(rows, lengths, p1_won, batch_scale=0.3)                   # ... is the lock-step replay
     assert np.abs(_np(a.theta) - _np(b.theta)).max() < 2e-6
+
+
+def test_streamed_replay_at_scale_matches_host_closed_form(bg, weights):
+    """The streamed replay on the kernels a large round runs on (matrix-pipe forward pass from 3 072 running slots, whole-row trace
+    workgroups from 8 192): 12 288 games through 3 072 and through 8 192 slots against the float64 closed form of the same
+    schedule (PyTorch on the GPU)."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n = 12288
+    env = bg.VecGame(n, seed=99)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=300, epsilon=0.1)
+    lengths = lengths.clone()
+    lengths[::13] = 0
+    turns = int(lengths.sum().item())
+    X = env.encode_rows(rows)                                   # float32 [T, n, 198], exact
+    Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.75)
+    for slots in (3072, 8192):
+        Lc = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.75, dtype=torch.float64)
+        sq_c, cnt_c = Lc.replay_stream(X, lengths, p1_won, slots=slots, batch_scale=24.0 / slots)
+        Ld.set_weights(weights)
+        sq_d, cnt_d = Ld.replay_rows(rows, lengths, p1_won, batch_scale=24.0 / slots, slots=slots)
+        th_c, th_d = _np(Lc.theta), _np(Ld.theta).astype(np.float64)
+        moved, d = np.abs(th_c - weights).max(), np.abs(th_d - th_c).max()
+        print("%d games through %d slots: weights moved by %.3g, device - host fp64 = %.3g, TD error sums %.6f / %.6f"
+              % (int((lengths > 0).sum()), slots, moved, d, sq_d, sq_c))
+        assert cnt_d == cnt_c == turns and abs(sq_d - sq_c) < 1e-4 * sq_c
+        assert moved > 1e-3 and d < 2e-5 * max(1.0, moved)
 
 
 def test_lazily_scaled_traces_equal_the_ordinary_pass(bg, weights):
