@@ -910,6 +910,69 @@ __global__ __launch_bounds__(ROOT3_THREADS) void traj_hidden_bf16x3_kernel(
     root3_body<TrajRowsFetch, false>(TrajRowsFetch{rows, gmeta, t, n_lanes, T}, n_rows, wl3, lut, b1, hidden);
 }
 
+// The same product for a FEW THOUSAND rows (the learner's mid-sized rounds: 1 024 .. 3 072 running slots = 2 048 .. 6 144 rows): a
+// workgroup of four waves per 32-row tile, wave c = hidden units 32 c .. 32 c + 31, the weight planes read straight from the L2
+// (39 coalesced 1-KB loads per wave, no LDS staging, no block barrier but the one behind the count LUT) -- the staged kernel above
+// gives such a step only 16 workgroups and each of them 86 KB of staging; the VALU forward kernel re-reads W1 per workgroup
+// (104 MB per step at 2 048 slots).  The MFMAs run in the staged kernel's order (K-step outer, plane inner): the same bits.
+constexpr int ROOT3D_THREADS = 256;
+__global__ __launch_bounds__(ROOT3D_THREADS) void traj_hidden_direct_kernel(
+    const uint4 *__restrict__ rows, const int4 *__restrict__ gmeta, long long t, long long n_lanes, long long T, long long n_rows,
+    const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut, const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    __shared__ uint2 sLut[16];
+    if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long tile = blockIdx.x;
+    const TrajRowsFetch fetch{rows, gmeta, t, n_lanes, T};
+    uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool row_ok = false;
+    if (tile * 32 + r < n_rows) {
+        uint4 u0, u1;
+        if (fetch.get(tile * 32 + r, u0, u1)) {
+            row_ok = true;
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+    }
+    const float bb = b1[32 * c + r];
+    const uint4 *wp = wl3 + (size_t)c * 64 + lane;
+    uint4 w[K16_STEPS][3];                                   // all 39 loads go out before the first MFMA needs one
+#pragma unroll
+    for (int s = 0; s < K16_STEPS; ++s)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) w[s][part] = wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
+    __syncthreads();
+    const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+    floatx16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < K16_STEPS; ++s) {
+        union { uint4 u; bf16x8 v; } a;
+        if (s < 12) {
+            const int pos = 2 * s + h + 1;
+            const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+            a.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {                                             // the tail K-step exactly as in root3_body
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
+            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            a.u = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+        }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            union { uint4 u; bf16x8 v; } wv;
+            wv.u = w[s][part];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wv.v, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long orow = tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+        if (orow < n_rows) hidden[orow * N_HID + 32 * c + r] = acc[j] + bb;
+    }
+}
+
 // position of W1[n][f] in ONE bf16 plane of the root3 layout (relayout_w1_bf16x3), in 16-bit units
 __host__ __device__ __forceinline__ int root3_plane_index(int n, int f)
 {

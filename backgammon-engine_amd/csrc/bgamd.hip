@@ -1590,7 +1590,9 @@ struct bgamd_td {
     TdView v{};
     bool has_weights = false, begun = false;
     int n_cu = 256;
-    long long mfma_min = 3072;             // running games from which the forward pass goes to the matrix pipe (BGAMD_TD_MFMA_MIN)
+    long long mfma_min = 24576;            // running games from which the forward pass uses the LDS-staged matrix-pipe kernel (BGAMD_TD_MFMA_MIN;
+                                           //   measured equal to the direct one from there up, slower below: 153 vs 132 ms per round at 3 072 slots)
+    long long direct_min = 512;            // ... from which it runs as one workgroup per 32-row tile, weights from the L2 (BGAMD_TD_DIRECT_MIN)
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
@@ -1664,10 +1666,11 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         td->n_cu = prop.multiProcessorCount;
-        td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 3072;
+        td->mfma_min = getenv("BGAMD_TD_MFMA_MIN") ? atoll(getenv("BGAMD_TD_MFMA_MIN")) : 24576;
     }
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
     if (getenv("BGAMD_TD_WIDE_MIN")) td->wide_min = atoll(getenv("BGAMD_TD_WIDE_MIN"));
+    if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
     HIPCHK(hipMemset(v.wr_cols, 0, (size_t)max_games * 4));
@@ -1825,13 +1828,23 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
                            (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
                            (const float *)(v.theta + TD_OFF_B1), v.hid);
         hipLaunchKernelGGL(td_epilogue_wave_kernel, grid1(n_active, 4), dim3(256), 0, s, v, (long long)t, (long long)n_active, alpha);
+    } else if (n_active >= td->direct_min) {
+        // mid-sized steps: the same product, a workgroup per 32-row tile and the weight planes straight from the L2 (bg_eval.h)
+        const long long n_rows = 2 * n_active;
+        hipLaunchKernelGGL(traj_hidden_direct_kernel, dim3((unsigned)((n_rows + 31) / 32)), dim3(ROOT3D_THREADS), 0, s, v.rows,
+                           (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
+                           (const float *)(v.theta + TD_OFF_B1), v.hid);
+        hipLaunchKernelGGL(td_epilogue_wave_kernel, grid1(n_active, 4), dim3(256), 0, s, v, (long long)t, (long long)n_active, alpha);
     } else if (n_active <= 8192)
         hipLaunchKernelGGL((td_forward_kernel<2, false>), grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     else
         hipLaunchKernelGGL((td_forward_kernel<4, false>), grid1(n_active, 4), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     // games per group: >= 4, and at most TD_MAX_GROUPS groups
     long long ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
-    if (ng < 4) ng = 4;
+#ifndef BG_TD_MIN_NG
+#define BG_TD_MIN_NG 4
+#endif
+    if (ng < BG_TD_MIN_NG) ng = BG_TD_MIN_NG;
     int n_groups = (int)((n_active + ng - 1) / ng);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (td->timing) {
@@ -1843,7 +1856,12 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         td->ev_used++;
         HIPCHK(hipEventRecord(e0, s));
     }
-    if (n_active >= td->wide_min) {
+    // whole-row workgroups take chunks of TD_CHUNK games: below wide_min they pay only when the chunks divide evenly over the CUs
+    // (a streamed replay through 2 048 or 4 096 slots: 143 vs 147 and 110 vs 118 ms per 65 536-game round)
+    const long long per_wave_of_blocks = (long long)td->n_cu * TD_CHUNK;
+    const bool wide_even = n_active >= per_wave_of_blocks && td->wide_min > per_wave_of_blocks &&
+                           n_active * 20 >= ((n_active + per_wave_of_blocks - 1) / per_wave_of_blocks) * per_wave_of_blocks * 19;
+    if (n_active >= td->wide_min || wide_even) {
         // large rounds: a workgroup per whole trace row and strided chunks of games (bg_learner.h)
         n_groups = (int)((n_active + TD_CHUNK - 1) / TD_CHUNK);
         if (n_groups > td->n_cu * BG_TD_WIDE_BPC) n_groups = td->n_cu * BG_TD_WIDE_BPC;

@@ -506,11 +506,11 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     assert dt_pool < 0.01
 
 
-@pytest.mark.parametrize("variant", ["default", "matrix_pipe", "wide", "matrix_pipe_and_wide"])
+@pytest.mark.parametrize("variant", ["default", "direct", "matrix_pipe", "direct_and_wide", "matrix_pipe_and_wide"])
 def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     """bgamd_td_begin_stream: k slots replay the round's games one after another.  Against the float64 host closed form of the
     same schedule (ragged lengths, lanes that are not replayed, a one-turn game), for 1, 7 and 64 slots, on the small-round
-    kernels and on the large-round ones (matrix-pipe forward pass + whole-row trace workgroups forced down to this size); a slot
+    kernels and on the large-round ones (the two matrix-pipe forward kernels, the whole-row trace workgroups: forced down to this size); a slot
     per game equals the lock-step replay; the (game, step) count is the round's turns; deterministic run to run."""
     from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
     n = 160
@@ -524,13 +524,15 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     Xr = env.encode_rows(rows).cpu().double()
     if "matrix_pipe" in variant:
         os.environ["BGAMD_TD_MFMA_MIN"] = "1"
+    if "direct" in variant:
+        os.environ["BGAMD_TD_DIRECT_MIN"] = "1"
     if "wide" in variant:
         os.environ["BGAMD_TD_WIDE_MIN"] = "1"
     try:
         mk = lambda: DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
         learners = [mk() for _ in range(3)]
     finally:
-        os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None)
+        os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None); os.environ.pop("BGAMD_TD_DIRECT_MIN", None)
     for slots in (1, 7, 64):
         Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.8, dtype=torch.float64)
         sq_c, cnt_c = Lc.replay_stream(Xr, lengths.cpu(), p1_won.cpu(), slots=slots, batch_scale=0.3)
@@ -557,7 +559,7 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
 
 
 def test_streamed_replay_at_scale_matches_host_closed_form(bg, weights):
-    """The streamed replay on the kernels a large round runs on (matrix-pipe forward pass from 3 072 running slots, whole-row trace
+    """The streamed replay on the kernels a large round runs on (matrix-pipe forward pass from 512 running slots, whole-row trace
     workgroups from 8 192): 12 288 games through 3 072 and through 8 192 slots against the float64 closed form of the same
     schedule (PyTorch on the GPU)."""
     from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
