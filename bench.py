@@ -139,6 +139,34 @@ def cpu_baseline(weights, budget_s=10.0):
     return out
 
 
+def training_round(bg, games, w):
+    """Extra information (outside the timed region of the contract): one training round of configs 4/5's per-GPU share -- self-play
+    of `games` games with the turn log from a frozen snapshot (train.py:527-547), then the TD(lambda) replay of the round on the
+    HIP learner kernels (bgamd_td_*): lock-step over the whole round, and streamed through 2 048 slots (the configuration the
+    quality study recommends: DESIGN.md §7).  Second run of each (the first pays allocations)."""
+    import torch
+    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
+    env = bg.VecGame(games, seed=5)
+    env.load_weights(w)
+    L = DeviceTDLambdaLearner(w, max_games=games, alpha=0.1, lam=0.7)
+
+    def timed(f):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    for _ in range(2):
+        (rows, lengths, won), dt_play = timed(lambda: play_round(env, max_plies=600, epsilon=0.05))
+    turns = int(lengths.sum().item())
+    out = {"games": games, "turns": turns, "selfplay_with_turn_log_ms": round(1e3 * dt_play, 2)}
+    for name, kw in (("lockstep_whole_round", {}), ("streamed_2048_slots", {"slots": 2048})):
+        for _ in range(2):
+            L.set_weights(w)
+            (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, batch_scale=24.0 / (kw.get("slots") or games), **kw))
+        out[name] = {"replay_ms": round(1e3 * dt, 2), "td_updates_per_s": round(cnt / dt, 1),
+                     "round_turns_per_s": round(turns / (dt + dt_play), 1)}
+    del L, env
+    return out
+
+
 def distinct_ratio(env, prec, sample_lanes=2048, samples=4):
     """Distinct afterstates U and raw reference-order candidates C per env step, measured after the timed region
     on lane samples of `samples` consecutive steps through the ordered enumeration (the throughput path never
@@ -172,6 +200,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-training-round", action="store_true", help="skip the extra training-round measurement (counter passes)")
     ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes and the CPU baseline, sample U on fewer lanes")
     a = ap.parse_args()
 
@@ -387,6 +416,11 @@ def main():
                               gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
     if alt:
         out["alt_modes"] = alt
+    if world == 1 and not a.quick and not a.no_training_round and a.games >= 4096:
+        try:
+            out["training_round"] = training_round(bg, a.games, w)
+        except Exception as e:                                  # extra information only: never costs the bench line
+            out["training_round"] = {"error": repr(e)[:200]}
     if world == 1 and not a.no_cpu_baseline and not a.quick:
         out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)
