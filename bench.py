@@ -200,7 +200,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-training-round", action="store_true", help="skip the extra training-round measurement (counter passes)")
+    ap.add_argument("--training-round", action="store_true", help="extra object in the line: one training round of configs 4/5's per-GPU share "
+                    "(self-play with the turn log + TD(lambda) replay).  Off by default: its self-play launches the step's kernels on shrinking "
+                    "batches, and a rocprofv3 --stats summary of the default command must average the timed workload only")
     ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes and the CPU baseline, sample U on fewer lanes")
     a = ap.parse_args()
 
@@ -416,7 +418,7 @@ def main():
                               gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
     if alt:
         out["alt_modes"] = alt
-    if world == 1 and not a.quick and not a.no_training_round and a.games >= 4096:
+    if world == 1 and a.training_round and a.games >= 4096:
         try:
             out["training_round"] = training_round(bg, a.games, w)
         except Exception as e:                                  # extra information only: never costs the bench line

@@ -33,4 +33,31 @@ sq = os.path.join(src, "sq_counters.txt")            # tools/sq_counters.sh <tag
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, f"{tag}_sq_counters.txt"))
     os.system(f"{sys.executable} tools/valu_occupancy.py {dst}/{tag}_sq_counters.txt --json {dst}/{tag.split('_')[0]}_valu_occupancy.json")
+drv = os.path.join(src, "bench_driver_style.json")    # tools/round_check.sh: bench.py --steps 20 --warmup 5, as the driver calls it
+if os.path.exists(drv):
+    shutil.copy(drv, os.path.join(dst, f"{tag}_bench_driver_style_steps20.json"))
+btr = os.path.join(src, "bench_with_training_round.json")
+if os.path.exists(btr):
+    shutil.copy(btr, os.path.join(dst, f"{tag}_bench_with_training_round.json"))
+tdb = os.path.join(src, "td_bench.txt")
+if os.path.exists(tdb):                               # the learner's summary: tools/td_bench.py, tools/train_breakdown.py, rocprof of a 65 536-game replay
+    with open(os.path.join(dst, f"{tag}_learner.txt"), "w") as f:
+        f.write(f"TD(lambda) learner kernels (csrc/bg_learner.h), MI355X, {tag} build.\n\n"
+                "tools/td_bench.py (play_round with epsilon 0.05, then one lock-step DeviceTDLambdaLearner.replay_rows of the whole round, HIP-event timing of the\n"
+                "trace kernel).  Column-sparse, lazily scaled traces: 'read' = W1 trace columns of features a game has activated so far, 'written' = those whose feature\n"
+                "is non-zero at the step (or all of them on the steps that fold the scale back in); 'moved' = bytes read + written; dense-equivalent = 204 808 B per update.\n\n")
+        f.write("".join(l for l in open(tdb) if l.startswith("n=") or l.startswith("   torch")))
+        tb = os.path.join(src, "train_breakdown.txt")
+        if os.path.exists(tb):
+            f.write("\ntools/train_breakdown.py: one 65 536-game training round (self-play from a frozen snapshot with the turn log, then its replay: lock-step whole,\n"
+                    "lock-step in sub-rounds, streamed through k slots)\n")
+            f.write("".join(l for l in open(tb) if "amdgpu" not in l))
+        ks = glob.glob(os.path.join(src, "td_stats", "*", "*kernel_stats.csv"))
+        if ks:
+            f.write("\nrocprofv3 --kernel-trace --stats of 'python3 tools/td_bench.py 65536' (two lock-step replays of one 65 536-game round; the env kernels are the self-play):\n")
+            for i, r in enumerate(csv.DictReader(open(ks[0]))):
+                if i >= 12:
+                    break
+                f.write("  %-64s calls %5s  total %9.2f ms  avg %8.1f us  %5s %%\n" % (r["Name"][:64], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
 print("profiles/ updated for", tag)

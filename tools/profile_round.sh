@@ -10,6 +10,6 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py > "$OUT/bench_under_rocprof.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline --no-training-round > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline --no-training-round > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 python3 -c "import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['avg_ms'])"

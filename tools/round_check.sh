@@ -12,4 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/td_stats
 grep "^n=" gpurun_out/$TAG/td_bench.txt | cut -c1-120
 python tools/train_breakdown.py 65536 0 4096 2048 s8192 s4096 s2048 s1024 > gpurun_out/$TAG/train_breakdown.txt 2>&1; grep -v amdgpu gpurun_out/$TAG/train_breakdown.txt | cut -c1-200
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_driver_style.json
+python bench.py --training-round --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_with_training_round.json
 python -c "import json; d=json.load(open('gpurun_out/$TAG/bench_driver_style.json')); print('driver-style bench:', d['value'], d['ms_per_step'], d['timed_regions'], d['region_ms'], d['roofline']['frac'])"
