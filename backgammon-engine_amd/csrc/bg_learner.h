@@ -575,7 +575,8 @@ constexpr int TD_WIDE_CPG = TD_WIDE_THREADS / 32;             // columns per k
 #ifndef BG_TD_WIDE_GPI
 #define BG_TD_WIDE_GPI 2
 #endif
-template <bool FIRST>
+// NT: nontemporal loads / stores (rounds whose traces stream from HBM); off where the active columns fit the Infinity Cache
+template <bool FIRST, bool NT>
 __global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide_kernel(TdView v, long long n_active, float emul, float ginv, float cmul, int full)
 {
     constexpr int GPI = BG_TD_WIDE_GPI;
@@ -645,7 +646,10 @@ __global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide
 #pragma unroll
                 for (int k = 0; k < TD_WIDE_K; ++k) {
                     ev[u][k] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
-                    if ((rd[u] >> k) & 1u) ev[u][k] = __builtin_nontemporal_load(reinterpret_cast<const td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)));
+                    if ((rd[u] >> k) & 1u) {
+                        const td_f32x4 *ep = reinterpret_cast<const td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4));
+                        ev[u][k] = NT ? __builtin_nontemporal_load(ep) : *ep;
+                    }
                 }
             }
 #pragma unroll
@@ -684,8 +688,10 @@ __global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide
                         x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (t_w1 ? xj : xfix[3])) * ginv);
                         wr = !t_w1 || xj != 0.0f;
                     }
-                    if (full || wr || !((rd[u] >> k) & 1u))
-                        __builtin_nontemporal_store(x, reinterpret_cast<td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)));
+                    if (full || wr || !((rd[u] >> k) & 1u)) {
+                        td_f32x4 *ep = reinterpret_cast<td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4));
+                        if (NT) __builtin_nontemporal_store(x, ep); else *ep = x;
+                    }
                     acc[k].x = fmaf(cf, x.x, acc[k].x);
                     acc[k].y = fmaf(cf, x.y, acc[k].y);
                     acc[k].z = fmaf(cf, x.z, acc[k].z);

@@ -1593,6 +1593,7 @@ struct bgamd_td {
     long long mfma_min = 24576;            // running games from which the forward pass uses the LDS-staged matrix-pipe kernel (BGAMD_TD_MFMA_MIN;
                                            //   measured equal to the direct one from there up, slower below: 153 vs 132 ms per round at 3 072 slots)
     long long direct_min = 512;            // ... from which it runs as one workgroup per 32-row tile, weights from the L2 (BGAMD_TD_DIRECT_MIN)
+    long long nt_min = 8192;               // ... from which the whole-row trace pass uses nontemporal loads / stores (BGAMD_TD_NT_MIN)
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
@@ -1670,6 +1671,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     }
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
     if (getenv("BGAMD_TD_WIDE_MIN")) td->wide_min = atoll(getenv("BGAMD_TD_WIDE_MIN"));
+    if (getenv("BGAMD_TD_NT_MIN")) td->nt_min = atoll(getenv("BGAMD_TD_NT_MIN"));
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
@@ -1866,10 +1868,13 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         n_groups = (int)((n_active + TD_CHUNK - 1) / TD_CHUNK);
         if (n_groups > td->n_cu * BG_TD_WIDE_BPC) n_groups = td->n_cu * BG_TD_WIDE_BPC;
         if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
+        const bool nt = n_active >= td->nt_min;
         if (t == 0)
-            hipLaunchKernelGGL(td_trace_wide_kernel<true>, dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);
+            hipLaunchKernelGGL((td_trace_wide_kernel<true, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);
+        else if (nt)
+            hipLaunchKernelGGL((td_trace_wide_kernel<false, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
         else
-            hipLaunchKernelGGL(td_trace_wide_kernel<false>, dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
+            hipLaunchKernelGGL((td_trace_wide_kernel<false, false>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
     } else if (t == 0)
         hipLaunchKernelGGL(td_trace_kernel<true>, dim3(TD_SLICES, n_groups), dim3(TD_TRACE_THREADS), 0, s, v, (long long)n_active,
                            (int)ng, emul, ginv, cmul, 1);
