@@ -448,6 +448,166 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     }
 }
 
+// The forward pass of a mid-sized step in ONE launch: traj_hidden_direct_kernel's product (a workgroup of four waves per 32-row tile =
+// 16 slots x {s_t, s_{t+1}}, wave c = hidden units 32 c .. 32 c + 31, weight planes straight from the L2) with the epilogue on the
+// accumulators -- σ, the W2 dot through LDS (32 rows x 128 products, 8 threads per row), δ, g, coef, the factor rows, the masks, the
+// slot's next game: no `hid` round trip, no second launch (5.9 us + a kernel boundary of the ~49 us step at 2 048 slots).
+constexpr int TD_FUSED_GAMES = 16;
+__global__ __launch_bounds__(ROOT3D_THREADS) void td_forward_mfma_kernel(TdView v, long long t, long long n_active, double alpha)
+{
+    constexpr int G = TD_FUSED_GAMES;
+    __shared__ uint2 sLut[16];
+    __shared__ float sd[2 * G][N_HID + 1];
+    __shared__ uint32_t srow[G][8], smask[G][TD_MASK_WORDS];
+    __shared__ float outs[2 * G], gs[G];
+    __shared__ unsigned int s_colsg[G], s_wrg[G];
+    __shared__ int adv[G], lives[G];
+    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long i0 = (long long)blockIdx.x * G;
+    const long long n_rows = 2 * n_active;
+    if (tid < 16) sLut[tid] = v.lut[tid];
+    if (tid < G) { s_colsg[tid] = 0; s_wrg[tid] = 0; adv[tid] = 0; lives[tid] = 0; }
+    if (tid < G * TD_MASK_WORDS) (&smask[0][0])[tid] = 0;
+    const TrajRowsFetch fetch{v.rows, v.gmeta, t, v.n_lanes, v.T};
+    uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool row_ok = false;
+    if (i0 * 2 + r < n_rows) {
+        uint4 u0, u1;
+        if (fetch.get(i0 * 2 + r, u0, u1)) {
+            row_ok = true;
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+    }
+    if (c == 0 && h == 0 && (r & 1) == 0) {                       // the 32-byte row of s_t of game r / 2 (zero: no running game)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) srow[r >> 1][k] = p[k];
+    }
+    const int n = 32 * c + r;
+    const float bb = v.theta[TD_OFF_B1 + n], w2n = v.theta[TD_OFF_W2 + n], b2 = v.theta[TD_OFF_B2];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(v.wl3) + (size_t)c * 64 + lane;
+    uint4 w[K16_STEPS][3];
+#pragma unroll
+    for (int s = 0; s < K16_STEPS; ++s)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) w[s][part] = wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
+    __syncthreads();
+    const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+    floatx16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < K16_STEPS; ++s) {
+        union { uint4 u; bf16x8 v; } a;
+        if (s < 12) {
+            const int pos = 2 * s + h + 1;
+            const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+            a.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
+            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            a.u = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+        }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            union { uint4 u; bf16x8 v; } wv;
+            wv.u = w[s][part];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wv.v, acc, 0, 0, 0);
+        }
+    }
+    // accumulator j of this lane = tile row (j & 3) + 8 (j >> 2) + 4 h (row 2 g + s: state s of game g), hidden unit n
+    float hv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        hv[j] = td_sigmoid(acc[j] + bb);
+        sd[(j & 3) + 8 * (j >> 2) + 4 * h][n] = w2n * hv[j];
+    }
+    // ever-active feature masks: thread = (game, two board points | tail)
+    {
+        const int g = tid >> 4, q = tid & 15;
+        if (i0 + g < n_active) {
+#pragma unroll
+            for (int pt = q; pt < 25; pt += 16) {
+                const uint32_t bits = td_nonzero_bits(srow[g], pt);
+                if (bits) atomicOr(&smask[g][pt >> 2], bits << (8 * (pt & 3)));
+            }
+        }
+    }
+    __syncthreads();
+    {   // output unit: thread = (row, eighth of the hidden layer)
+        const int row = tid >> 3, e8 = tid & 7;
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < N_HID / 8; ++k) sum += sd[row][e8 * (N_HID / 8) + k];
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        if (e8 == 0) outs[row] = td_sigmoid(sum + b2);
+    }
+    __syncthreads();
+    if (tid < G) {                                                // δ, g, coef per game
+        const long long i = i0 + tid;
+        float g = 0.0f;
+        if (i < n_active) {
+            const int4 gm = v.gmeta[i];
+            const long long tl = t - gm.w;
+            if (tl < gm.y) {
+                const float val = outs[2 * tid], vnext = outs[2 * tid + 1];
+                const float z = gm.z ? 1.0f : 0.0f;
+                const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
+                g = val * (1.0f - val);
+                v.coef[i] = (float)(alpha * (double)delta);
+                v.sq[i] += (double)delta * (double)delta;
+                v.nupd[i] += 1u;
+                lives[tid] = 1 + (tl == 0 ? 1 : 0);
+                if (tl + 1 >= gm.y) adv[tid] = 1;
+            } else v.coef[i] = 0.0f;
+        }
+        gs[tid] = g;
+    }
+    __syncthreads();
+    // factor rows of the running games: db1 | g·h from the accumulators of s_t (even tile rows = even j)
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const int g = ((j & 3) + 8 * (j >> 2) + 4 * h) >> 1;
+        if (lives[g]) {
+            float *f = v.fac + (i0 + g) * TD_FLD;
+            const float gg = gs[g], hh = hv[j];
+            f[TD_F_DB1 + n] = (gg * w2n) * (1.0f - hh) * hh;
+            f[TD_F_GH + n] = gg * hh;
+        }
+    }
+    if (tid < G * 9) {
+        const int g = tid / 9, k = tid % 9;
+        if (lives[g]) {
+            float *f = v.fac + (i0 + g) * TD_FLD;
+            if (k < 8) f[TD_F_ROW + k] = __uint_as_float(srow[g][k]);
+            else f[TD_F_G] = gs[g];
+        }
+    }
+    if (tid < G * TD_MASK_WORDS) {
+        const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
+        const long long i = i0 + g;
+        if (i < n_active) {
+            const bool run = lives[g] != 0, first = lives[g] == 2;
+            uint32_t now = smask[g][wd];
+            const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);
+            const uint32_t nz = now & valid;
+            now = v.dense ? valid : nz;
+            if (!run) now = 0u;
+            const uint32_t old = (first || !run || wd == TD_FLAG_WORD) ? 0u : v.amask[i * TD_MASK_WORDS + wd];
+            v.amask[i * TD_MASK_WORDS + wd] = wd == TD_FLAG_WORD ? (run ? 1u : 0u) : (old | now);
+            v.anew[i * TD_MASK_WORDS + wd] = wd == TD_FLAG_WORD ? (first ? 1u : 0u) : (now & ~old);
+            atomicAdd(&s_colsg[g], (unsigned int)__popc(old | now));
+            atomicAdd(&s_wrg[g], (unsigned int)__popc(v.full_step ? (old | now) : (run ? (nz | (now & ~old)) : 0u)));
+        }
+    }
+    __syncthreads();
+    if (tid < G && i0 + tid < n_active) {
+        v.act_cols[i0 + tid] += s_colsg[tid];
+        v.wr_cols[i0 + tid] += s_wrg[tid];
+        if (adv[tid]) td_advance_slot(v, i0 + tid, (int)(t + 1));
+    }
+}
+
 // grid (TD_SLICES, n_groups); block 256 threads x float4 of the trace (internal order); `ng` games per group.
 // A thread owns four consecutive internal positions = ONE feature column j and four hidden units of it (or four of the
 // dense tail b1 | W2 | b2), for every game of its group: a W1 column that is not active in a game is skipped for that game

@@ -1592,6 +1592,7 @@ struct bgamd_td {
     int n_cu = 256;
     long long mfma_min = 24576;            // running games from which the forward pass uses the LDS-staged matrix-pipe kernel (BGAMD_TD_MFMA_MIN;
                                            //   measured equal to the direct one from there up, slower below: 153 vs 132 ms per round at 3 072 slots)
+    bool fused = true;                     // ... with its epilogue in the same launch (BGAMD_TD_FUSED=0: two launches)
     long long direct_min = 512;            // ... from which it runs as one workgroup per 32-row tile, weights from the L2 (BGAMD_TD_DIRECT_MIN)
     long long nt_min = 8192;               // ... from which the whole-row trace pass uses nontemporal loads / stores (BGAMD_TD_NT_MIN)
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
@@ -1672,6 +1673,7 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
     if (getenv("BGAMD_TD_WIDE_MIN")) td->wide_min = atoll(getenv("BGAMD_TD_WIDE_MIN"));
     if (getenv("BGAMD_TD_NT_MIN")) td->nt_min = atoll(getenv("BGAMD_TD_NT_MIN"));
+    td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
@@ -1830,6 +1832,9 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
                            (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
                            (const float *)(v.theta + TD_OFF_B1), v.hid);
         hipLaunchKernelGGL(td_epilogue_wave_kernel, grid1(n_active, 4), dim3(256), 0, s, v, (long long)t, (long long)n_active, alpha);
+    } else if (n_active >= td->direct_min && td->fused) {
+        // mid-sized steps: the product and its epilogue in one launch (bg_learner.h)
+        hipLaunchKernelGGL(td_forward_mfma_kernel, grid1(n_active, TD_FUSED_GAMES), dim3(ROOT3D_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha);
     } else if (n_active >= td->direct_min) {
         // mid-sized steps: the same product, a workgroup per 32-row tile and the weight planes straight from the L2 (bg_eval.h)
         const long long n_rows = 2 * n_active;

@@ -506,7 +506,7 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     assert dt_pool < 0.01
 
 
-@pytest.mark.parametrize("variant", ["default", "direct", "matrix_pipe", "direct_and_wide", "matrix_pipe_and_wide"])
+@pytest.mark.parametrize("variant", ["default", "direct", "direct_unfused", "matrix_pipe", "direct_and_wide", "matrix_pipe_and_wide"])
 def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     """bgamd_td_begin_stream: k slots replay the round's games one after another.  Against the float64 host closed form of the
     same schedule (ragged lengths, lanes that are not replayed, a one-turn game), for 1, 7 and 64 slots, on the small-round
@@ -526,13 +526,15 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
         os.environ["BGAMD_TD_MFMA_MIN"] = "1"
     if "direct" in variant:
         os.environ["BGAMD_TD_DIRECT_MIN"] = "1"
+    if "unfused" in variant:
+        os.environ["BGAMD_TD_FUSED"] = "0"
     if "wide" in variant:
         os.environ["BGAMD_TD_WIDE_MIN"] = "1"
     try:
         mk = lambda: DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
         learners = [mk() for _ in range(3)]
     finally:
-        os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None); os.environ.pop("BGAMD_TD_DIRECT_MIN", None)
+        os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None); os.environ.pop("BGAMD_TD_DIRECT_MIN", None); os.environ.pop("BGAMD_TD_FUSED", None)
     for slots in (1, 7, 64):
         Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.8, dtype=torch.float64)
         sq_c, cnt_c = Lc.replay_stream(Xr, lengths.cpu(), p1_won.cpu(), slots=slots, batch_scale=0.3)
