@@ -48,6 +48,8 @@ def main():
                     "(every training step sums the updates of that many games at different plies; overrides --sub-round)")
     ap.add_argument("--scale-games", type=float, default=24.0, help="every game's update is scaled by min(1, this / games per "
                     "(sub-)round): 24 = the summed update of a reference-sized round (round_size = workers <= 24, train.py:307-312)")
+    ap.add_argument("--scale-warmup", type=float, default=0.0, help="first round's --scale-games (doubling every round up to --scale-games): "
+                    "the summed update of a large step overshoots while the net is random and every game pushes the same way (0 = no warm-up)")
     ap.add_argument("--arena", type=int, default=1024, help="lanes of the evaluation arena (2 games per lane, sides alternated)")
     ap.add_argument("--max-plies", type=int, default=600)
     ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
@@ -98,7 +100,8 @@ def main():
             assert first_dice is None or not torch.equal(d, first_dice), "two rounds rolled the same dice"
             first_dice = d
         sub = a.slots if a.slots > 0 else a.sub_round if a.sub_round > 0 else a.games
-        scale = min(1.0, a.scale_games / (min(sub, a.games) * world))
+        sg = a.scale_games if a.scale_warmup <= 0 else min(a.scale_games, a.scale_warmup * 2.0 ** r)
+        scale = min(1.0, sg / (min(sub, a.games) * world))
         if a.host_learner:
             sq, cnt = L.replay(env.encode_rows(rows), lengths, p1_won, group=group, batch_scale=scale)
         else:

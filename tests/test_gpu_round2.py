@@ -428,7 +428,7 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
         assert np.array_equal(r[k]["states"], st[k * lanes:(k + 1) * lanes]), k
         assert np.array_equal(r[k]["turns"], tn[k * lanes:(k + 1) * lanes]), k
         assert list(r[k]["totals"]) == [sw["steps"], sw["games_finished"], sw["p1_wins"]]       # all-reduced counters
-    assert np.array_equal(r[0]["theta"], r[1]["theta"])        # replicas identical after two rounds of all-reduced updates
+    assert np.array_equal(r[0]["theta"], r[1]["theta"])        # replicas identical after three rounds of all-reduced updates (lock-step, sub-rounds, streamed)
     assert np.abs(r[0]["theta"] - weights).max() > 1e-4
     assert not np.array_equal(r[0]["lengths"], r[1]["lengths"])   # the two shards played different games
     assert r[0]["learner"][1] > 0 and r[1]["learner"][1] > 0
