@@ -16,6 +16,12 @@ import ctypes as C
 import enum
 import os
 
+# The greedy step runs its root pass on a second stream beside the doubles plies; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4)
+# hardware queues, and a process that also holds an RCCL communicator has more streams than that: the env's two then share a queue and
+# every step loses the overlap (0.153 -> 0.167 ms at 65 536 lanes).  The variable is read when the HIP runtime starts: this default
+# takes effect when the package is imported before the first GPU call (multi-rank launchers: export it).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

@@ -23,6 +23,12 @@ for p in (ROOT, os.path.join(ROOT, "backgammon-engine_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# The step overlaps its root pass with the doubles plies on a second stream.  ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4)
+# hardware queues; an RCCL communicator brings streams of its own, the env's two then share a queue and the overlap is gone
+# (measured: 0.153 -> 0.167 ms per step with nothing but `init_process_group("nccl")` added; 0.153 again with 8 queues).
+# Read when the HIP runtime starts, so it is set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -254,9 +260,10 @@ def main():
         t0 = time.perf_counter()
         env.run_greedy(a.steps, precision=prec)   # EXACTLY a.steps env steps (one call: consecutive steps share launches)
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0             # this rank's steps are done; the MAX over ranks is taken below (aggregate)
         if use_dist:
-            dist.barrier()
-        return time.perf_counter() - t0
+            dist.barrier()                        # the closing barrier of the bracket: its own latency (an RCCL all-reduce + a host
+        return dt                                 # round trip, ~0.4 ms of a 3 ms region) is not part of anybody's K steps
 
     # A region shorter than 10 ms (the driver's --steps 20 is 3 ms) is at the mercy of one scheduling hiccup: it is
     # then repeated -- every repetition is again EXACTLY a.steps steps between barrier + synchronize -- and the MEDIAN

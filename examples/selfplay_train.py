@@ -11,6 +11,7 @@ Not the reference's training CLI (out of scope) -- a 60-line demonstration that 
 """
 import argparse
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: backgammon_env/__init__.py says why
 import sys
 import time
 

@@ -7,6 +7,7 @@ Started as a FRESH process (nothing GPU-related is inherited), joins a gloo grou
      (ONE all-reduce of the 25 601-float update per training step)                    -> its replica's weights
 and writes both to <out>/rank<r>.npz."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: backgammon_env/__init__.py says why
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
