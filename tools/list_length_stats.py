@@ -1,3 +1,6 @@
+"""How much of the value net's gather work is the wave-wide maximum?  Per 64-row tile the incremental kernel runs as many gather passes as its
+LONGEST (feature, delta) list.  Prints, at three game phases of a 65 536-lane env: the mean list length, the mean over tiles of the longest list (arena order),
+and what rows sorted by length inside windows of 256 .. 16 384 rows (or globally) would need.  -> profiles/r02_list_length_stats.txt."""
 import sys, numpy as np, torch
 sys.path.insert(0, "backgammon-engine_amd")
 import backgammon_env as bg

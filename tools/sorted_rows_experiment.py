@@ -1,3 +1,7 @@
+"""Upper bound of what binning rows by list length could buy the value-net kernel: the afterstates of one 65 536-lane step through
+bgamd_evaluate_incremental in arena order, stably sorted into length classes of two, and sorted by exact length (same values, bit for bit); run under
+rocprofv3 --kernel-trace and read the eval_rows_delta_kernel durations.  python tools/sorted_rows_experiment.py arena|sorted|exact
+-> profiles/r02_sorted_rows_experiment.txt."""
 import sys, numpy as np, torch
 sys.path.insert(0, "backgammon-engine_amd")
 import backgammon_env as bg
