@@ -8,6 +8,7 @@ import backgammon_env as bg
 from backgammon_env.learner import DeviceTDLambdaLearner, play_round
 w = np.fromfile(os.path.join(ROOT, "tests/golden/tdgammonNEW100k.f32"), dtype=np.float32)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+SPLIT = os.environ.get("TB_SPLIT_APPLY") == "1"      # the distributed route on one rank: step / (all-reduce) / apply from a Python loop
 subs = sys.argv[2:] or ["0", "4096", "2048", "s4096", "s2048"]
 env = bg.VecGame(n, seed=5); env.load_weights(w)
 L = DeviceTDLambdaLearner(w, max_games=n, alpha=0.1, lam=0.7)
@@ -24,7 +25,7 @@ for arg in subs:
     for rep in range(2):
         L.set_weights(w)
         (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, batch_scale=min(1.0, 24.0 / k), sub_round=0 if stream else sub,
-                                                    slots=sub if stream else 0))
+                                                    slots=sub if stream else 0, split_apply=SPLIT))
     if stream:
         from backgammon_env.learner import stream_schedule
         _, _, n_steps, kk = stream_schedule(lengths.to(torch.int32), sub)
