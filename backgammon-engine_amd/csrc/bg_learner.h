@@ -1,19 +1,24 @@
 // bg_learner.h -- TD(lambda) learner kernels: the reference's apply_td_updates
-// (pysrc/TD(λ) model/train.py:124-172) with the eligibility traces of model.py:48-53, as a lock-step replay
-// over the turn index of many games.  Per step t, for every game still running (the games are ordered by
-// decreasing length, so the running ones are a prefix of the order):
+// (pysrc/TD(λ) model/train.py:124-172) with the eligibility traces of model.py:48-53, as a replay in training steps over
+// SLOTS: a slot holds one game at a time (gmeta: lane, length, winner, the step the game started at).  Lock-step replay
+// (bgamd_td_begin): one game per slot, all starting at step 0, ordered by decreasing length, so the running ones are a
+// prefix.  Streamed replay (bgamd_td_begin_stream): a slot takes the next game of its queue the step after its last one
+// ended (td_advance_slot).  Per step t, for every slot with a running game:
 //
-//   td_forward_kernel  8 games per workgroup, thread per hidden unit: decode x_t and x_{t+1} from the 32-byte
-//                      trajectory rows, h = σ(W1 x + b1), v = σ(W2 h + b2) for both, δ (train.py:136-141, terminal
-//                      step train.py:165-166), g = v(1-v), the factors of the closed-form gradient
+//   forward pass       x_t and x_{t+1} from the 32-byte trajectory rows, h = σ(W1 x + b1), v = σ(W2 h + b2) for both, δ
+//                      (train.py:136-141, terminal step train.py:165-166), g = v(1-v), the factors of the closed-form gradient
 //                        ∇W1 = db1 ⊗ x, ∇b1 = db1 = g W2 ⊙ h ⊙ (1-h), ∇W2 = g h, ∇b2 = g
-//                      written as one 464-float "factor row" per game, coef = fp32(α δ) with α δ formed in
-//                      float64 first (train.py:147,160,169)
-//   td_trace_kernel    the HBM-bound pass: e ← λ e + ∇ (model.py:52-53 semantics, train.py:150-158), one read and
-//                      one write of the 25 601-float trace of every running game, and in the same pass the
-//                      block's share of Σ_g coef_g · e_g (train.py:159-161) -> partial sums per game group
-//   td_reduce_kernel   Σ over game groups -> the 25 601-float update; θ += update (or hand it to the caller for
-//                      the one all-reduce of the step), W1 re-transposed for the next forward
+//                      written as one 272-float "factor row" per slot (the row of s_t | db1 | g·h | g), coef = fp32(α δ) with
+//                      α δ formed in float64 first (train.py:147,160,169), the slot's ever-active feature mask.  By size of the step:
+//                        td_forward_kernel<GB>     < 512 slots: GB slots per workgroup, thread per hidden unit, all on the VALUs
+//                        td_forward_mfma_kernel    512 .. 24 575: W1 x on the matrix pipe (bf16 x 3, weights from the L2), epilogue fused
+//                        traj_hidden_bf16x3_kernel + td_epilogue_wave_kernel   larger: the env's LDS-staged root pass, a wave per slot
+//   trace pass         the HBM-bound one: e ← λ e + ∇ (model.py:52-53 semantics, train.py:150-158) and, in the same pass, the
+//                      workgroup's share of Σ_g coef_g · e_g (train.py:159-161) -> partial sums; column-sparse and lazily
+//                      scaled (below).  td_trace_kernel (slices x groups of games) below 8 192 slots, td_trace_wide_kernel
+//                      (a workgroup per whole trace row) from there and where the chunks divide evenly
+//   td_reduce_kernel   Σ over the partial sums -> the 25 601-float update; θ += update (or hand it to the caller for
+//                      the one all-reduce of the step), W1 re-transposed and re-split for the next forward
 //
 // Algorithmic bytes per (game, step): 2 · 25 601 · 4 = 204 808 B of trace traffic (SURVEY §8d "learner") for DENSE traces.
 //
@@ -725,9 +730,6 @@ __global__ __launch_bounds__(TD_TRACE_THREADS) void td_trace_kernel(TdView v, lo
 #ifndef BG_TD_WIDE_W
 #define BG_TD_WIDE_W 512
 #endif
-#ifndef BG_TD_WIDE_BPC
-#define BG_TD_WIDE_BPC 1
-#endif
 constexpr int TD_WIDE_THREADS = BG_TD_WIDE_W;                 // 512 or 1024
 constexpr int TD_WIDE_KL = 6144 / TD_WIDE_THREADS;            // the k of the tail group (columns 192..197 | b1 | W2 | b2)
 constexpr int TD_WIDE_K = TD_WIDE_KL + 1;
@@ -737,7 +739,7 @@ constexpr int TD_WIDE_CPG = TD_WIDE_THREADS / 32;             // columns per k
 #endif
 // NT: nontemporal loads / stores (rounds whose traces stream from HBM); off where the active columns fit the Infinity Cache
 template <bool FIRST, bool NT>
-__global__ __launch_bounds__(TD_WIDE_THREADS, BG_TD_WIDE_BPC) void td_trace_wide_kernel(TdView v, long long n_active, float emul, float ginv, float cmul, int full)
+__global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_wide_kernel(TdView v, long long n_active, float emul, float ginv, float cmul, int full)
 {
     constexpr int GPI = BG_TD_WIDE_GPI;
     __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][TD_FLD];

@@ -1871,7 +1871,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     if (n_active >= td->wide_min || wide_even) {
         // large rounds: a workgroup per whole trace row and strided chunks of games (bg_learner.h)
         n_groups = (int)((n_active + TD_CHUNK - 1) / TD_CHUNK);
-        if (n_groups > td->n_cu * BG_TD_WIDE_BPC) n_groups = td->n_cu * BG_TD_WIDE_BPC;
+        if (n_groups > td->n_cu) n_groups = td->n_cu;
         if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
         const bool nt = n_active >= td->nt_min;
         if (t == 0)
