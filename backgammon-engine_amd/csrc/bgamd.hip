@@ -20,6 +20,7 @@
 #include "../../include/bgamd.h"
 #include "bg_board.h"
 #include "bg_eval.h"
+#include "bg_eval_mfma.h"
 #include "bg_learner.h"
 #include "bg_movegen.h"
 #include "bg_staged.h"
@@ -616,6 +617,9 @@ struct bgamd_env {
     float *d_w[2] = {nullptr, nullptr};    // raw weights 25601, two slots (head-to-head: one per side)
     float4 *d_wl[2] = {nullptr, nullptr};  // fp32 MFMA layout [99][64]
     float4 *d_wt[2] = {nullptr, nullptr};  // W1^T [198][132] for the incremental evaluator
+    uint4 *d_wm[2] = {nullptr, nullptr};   // W1^T as f16 hi | lo dwords [198][4][32] for the MFMA delta kernel (bg_eval_mfma.h)
+    bool wm_ok[2] = {false, false};        // the slot's table fits f16 (else the VALU delta kernel evaluates that slot)
+    bool mfma_delta = true;                // BGAMD_VALU_DELTA=1: round 2's eval_rows_delta_kernel instead
     uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term)
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
@@ -747,6 +751,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
+    env->mfma_delta = getenv("BGAMD_VALU_DELTA") == nullptr;
     // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
     // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
@@ -789,6 +794,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
         HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
         HIPCHK(hipMalloc(&env->d_wt[k], DELTA_W_FLOATS * 4));
+        HIPCHK(hipMalloc(&env->d_wm[k], MD_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl3[k], 3 * EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
@@ -831,6 +837,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DELTA_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)eval_rows_mdelta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)root_hidden_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROOT3_LDS_TOTAL));
     return BGAMD_OK;
 }
@@ -841,7 +848,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     if (env->d_scalar) hipFree(env->d_scalar);
@@ -1152,6 +1159,9 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     std::vector<float> wt((size_t)DELTA_W_FLOATS);
     relayout_w1_delta(h_weights, wt.data());
     HIPCHK(hipMemcpy(env->d_wt[slot], wt.data(), DELTA_W_FLOATS * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> wmd((size_t)MD_W_DWORDS);
+    env->wm_ok[slot] = relayout_w1_mdelta(h_weights, wmd.data()) >= 0;
+    HIPCHK(hipMemcpy(env->d_wm[slot], wmd.data(), MD_W_BYTES, hipMemcpyHostToDevice));
     std::vector<uint16_t> wl3((size_t)3 * K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16x3(h_weights, wl3.data());
     HIPCHK(hipMemcpy(env->d_wl3[slot], wl3.data(), 3 * EVAL16_W_BYTES, hipMemcpyHostToDevice));
@@ -1305,6 +1315,14 @@ struct GreedyRun {
             // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
             long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
             dblocks = dblocks < 1 ? 1 : (dblocks > ss.n_cu ? ss.n_cu : dblocks);
+            if (env->mfma_delta && env->wm_ok[slot])
+                hipLaunchKernelGGL(eval_rows_mdelta_kernel, dim3((unsigned)dblocks), dim3(MD_THREADS), MD_LDS_TOTAL, se,
+                                   (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
+                                   (const uint4 *)env->d_wm[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
+                                   env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS],
+                                   fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT, &env->v.counters[C_ERR],
+                                   (unsigned long long)ERRF_DELTA);
+            else
             hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, se,
                                (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                                (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
@@ -1531,6 +1549,13 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
                        sv.root_hidden);
     long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;
     dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
+    if (env->mfma_delta && env->wm_ok[slot])
+        hipLaunchKernelGGL(eval_rows_mdelta_kernel, dim3((unsigned)dblocks), dim3(MD_THREADS), MD_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
+                           (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const uint4 *)env->d_wm[slot],
+                           w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden, d_values, (const uint2 *)sv.u_info, sv.best,
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0, &env->v.counters[C_ERR],
+                           (unsigned long long)ERRF_DELTA);
+    else
     hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
                        (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const float4 *)env->d_wt[slot],
                        w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden, d_values, (const uint2 *)sv.u_info, sv.best,

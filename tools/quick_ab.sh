@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# quick same-box A/B of the value-net stage: the library as built vs BGAMD_VALU_DELTA=1 (round 2's kernel), interleaved
+# usage (on the GPU box): bash tools/quick_ab.sh TAG [rounds]
+TAG=${1:?tag}; R=${2:-2}
+mkdir -p gpurun_out/$TAG
+for i in $(seq 1 $R); do
+  python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/mfma_$i.json
+  BGAMD_VALU_DELTA=1 python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/valu_$i.json
+done
+python - <<PY
+import json,glob
+for k in ("mfma","valu"):
+    for f in sorted(glob.glob("gpurun_out/$TAG/%s_*.json"%k)):
+        d=json.load(open(f)); e=d["kernels"]["eval"]
+        print(k, "step %.4f ms  value-net kernel %.4f ms  stage %.4f  steps/s %.1fM" % (d["ms_per_step"], e["avg_ms"], e.get("value_net_stage_ms",0), d["value"]/1e6))
+PY
