@@ -45,7 +45,7 @@ def set_seed(seed: int):
     """Seeds the dice of scalar Game objects created afterwards (the reference cannot be seeded)."""
     global _seed, _next_scalar_id
     _seed = int(seed) & (2 ** 64 - 1)
-    _next_scalar_id = 0
+    _next_scalar_id = 0                  # (pooled envs are re-seeded when they are handed out: Game.__init__)
 
 
 def _stream():
@@ -152,6 +152,11 @@ class VecGame:
         m = self._dev(mask, torch.int32, (self.n,))
         _capi.check(self._lib.bgamd_env_reset_lanes(self._h, _ptr(m), _stream()), "reset_lanes")
         torch.cuda.current_stream().synchronize()
+
+    def reseed(self, seed: int, lane_offset: int = 0, lane_stride: int = 0, null_stream: bool = False):
+        """The dice streams of a freshly created env with these arguments, on this one (episode 0, start position)."""
+        st = None if null_stream else _stream()
+        _capi.check(self._lib.bgamd_env_reseed(self._h, int(seed) & (2 ** 64 - 1), int(lane_offset), int(lane_stride), st), "reseed")
 
     def set_states(self, states28=None, turn=None):
         s = self._dev(states28, torch.int32, (self.n, 28)) if states28 is not None else None
@@ -404,9 +409,13 @@ class Game:
         dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
         pool = _POOL.setdefault(dev, [])
         if pool:
-            self._v = pool.pop()                              # a fresh game on a pooled env: its own dice stream (episode =
-            self._v.reset(episode=_next_scalar_id + 1)        # a new global game id), last_dice {1,1} (game.hpp:44), no
-            self._v.reset_stats()                             # error flags left over from the previous owner
+            # a fresh game on a pooled env: the dice a NEW env would roll (seed of set_seed(), game id = the running count),
+            # last_dice {1,1} (game.hpp:44), no error flags left over from the previous owner -- issued on the NULL stream,
+            # where the host-argument surface (bgamd_game_*) runs: a caller inside `with torch.cuda.stream(s)` must not see
+            # the reset overtake the set_state that follows
+            self._v = pool.pop()
+            self._v.reseed(_seed, _next_scalar_id, 1 << 40, null_stream=True)
+            _capi.check(self._v._lib.bgamd_env_reset_stats(self._v._h, None), "reset_stats")
         else:
             self._v = VecGame(1, device=dev, seed=_seed, lane_offset=_next_scalar_id, lane_stride=1 << 40,
                               arena_rows=self._ARENA)
@@ -428,9 +437,18 @@ class Game:
     def _dirty(self):
         self._snap = None
 
+    @staticmethod
+    def _order():
+        """The bgamd_game_* calls run on the NULL stream and torch's side streams are non-blocking: work this thread queued
+        on its current stream for the same env (step_greedy of make_move, last_choice) has to be done first."""
+        st = torch.cuda.current_stream()
+        if st != torch.cuda.default_stream(st.device):
+            st.synchronize()
+
     def _s(self):
         """state28 | turn | die1 | die2 | flags: ONE call of the host-argument scalar surface (bgamd_game_snapshot)."""
         if self._snap is None:
+            self._order()
             buf = (C.c_int32 * 32)()
             _capi.check(self._v._lib.bgamd_game_snapshot(self._v._h, buf), "snapshot")
             self._snap = list(buf)
@@ -438,6 +456,7 @@ class Game:
 
     def _put(self, state28=None, turn=-1):
         arr = (C.c_int32 * 28)(*[int(v) for v in state28]) if state28 is not None else None
+        self._order()
         _capi.check(self._v._lib.bgamd_game_set_state(self._v._h, arr, int(turn)), "set_state")
         self._dirty()
 
@@ -502,11 +521,13 @@ class Game:
 
     # dice -------------------------------------------------------------------------------------
     def setDice(self, d1, d2):
+        self._order()
         _capi.check(self._v._lib.bgamd_game_set_dice(self._v._h, int(d1), int(d2)), "setDice")
         self._dirty()
 
     def roll_dice(self):
         d = (C.c_int32 * 2)()
+        self._order()
         _capi.check(self._v._lib.bgamd_game_roll(self._v._h, d), "roll_dice")
         self._dirty()
         return [int(d[0]), int(d[1])]
@@ -518,6 +539,7 @@ class Game:
     # rules --------------------------------------------------------------------------------------
     def legalMoves(self, player, die):
         pairs = (C.c_int8 * 52)()
+        self._order()
         k = _capi.check(self._v._lib.bgamd_game_legal_moves(self._v._h, int(player), int(die), pairs), "legalMoves")
         return [(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(k)]
 
@@ -527,6 +549,7 @@ class Game:
         for _ in range(2):
             st = np.empty((cap, 28), dtype=np.int32) if want_states else None
             sq, ln = np.empty((cap, 4, 2), dtype=np.int8), np.empty((cap,), dtype=np.int32)
+            self._order()
             k = _capi.check(self._v._lib.bgamd_game_enumerate(self._v._h, int(player), int(d1), int(d2),
                                                              st.ctypes.data_as(C.c_void_p) if want_states else None,
                                                              sq.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), cap), "enumerate")
@@ -544,6 +567,7 @@ class Game:
         return self._enumerate(player, die1, die2)
 
     def tryMove(self, player: Player, dice, origin, dest):
+        self._order()
         err = _capi.check(self._v._lib.bgamd_game_try_move(self._v._h, player.getNum(), int(dice), int(origin), int(dest)), "tryMove")
         if err == 0:
             self._dirty()

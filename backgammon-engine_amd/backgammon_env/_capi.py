@@ -30,6 +30,7 @@ SYMBOLS = [
     ("bgamd_env_num_games", C.c_int64, [_P]),
     ("bgamd_env_reset", C.c_int, [_P, _P]),
     ("bgamd_env_reset_episode", C.c_int, [_P, C.c_uint32, _P]),
+    ("bgamd_env_reseed", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     ("bgamd_env_reset_lanes", C.c_int, [_P, _P, _P]),
     ("bgamd_env_set_states", C.c_int, [_P, _P, _P, _P]),
     ("bgamd_env_get_states", C.c_int, [_P, _P, _P, _P]),

@@ -6,10 +6,14 @@ same method names and argument meaning, arithmetic in HIP kernels (encoder + MFM
 """
 from __future__ import annotations
 
+import itertools
+
 import numpy as np
 import torch
 
 from . import F32, Game, VecGame
+
+_TOKENS = itertools.count(1)       # one per model object, never reused (id() is, once a model has been freed)
 
 
 def flatten_state_dict(sd) -> np.ndarray:
@@ -26,6 +30,7 @@ class TDLGammonModel:
         self.lambda_decay = 0.7                        # model.py:46
         self._w = None
         self._version = 0
+        self._token = next(_TOKENS)
         self._ops = None                               # a small env used for stateless encode / evaluate
 
     # -- weights -------------------------------------------------------------------------------
@@ -54,9 +59,11 @@ class TDLGammonModel:
         self.lambda_decay = max(0.7, 0.9 * (0.96 ** (episode // 30000)))
 
     def _bind(self, env: VecGame):
-        if getattr(env, "_w_version", None) != (id(self), self._version):
+        # envs outlive their Game (the one-lane pool): the key must name THIS model for good, not an address that the next
+        # model may be given
+        if getattr(env, "_w_version", None) != (self._token, self._version):
             env.load_weights(self._w)
-            env._w_version = (id(self), self._version)
+            env._w_version = (self._token, self._version)
 
     def _op_env(self) -> VecGame:
         if self._ops is None:

@@ -30,16 +30,20 @@
 
 namespace bg {
 
-constexpr int MD_THREADS = 768;                         // 12 waves per CU (3 per SIMD): <= 168 VGPRs
+#ifndef BG_MD_THREADS
+#define BG_MD_THREADS 1024
+#endif
+constexpr int MD_THREADS = BG_MD_THREADS;               // 16 waves per CU (4 per SIMD): <= 128 VGPRs
 constexpr int MD_WAVES = MD_THREADS / 64;
 constexpr int MD_SLOTS = 32;                            // compact feature slots of a piece (4 K-steps of 8 features)
 constexpr int MD_W_DWORDS = N_IN * N_HID;               // [198][4][32] dwords: f16 hi | f16 lo << 16
 constexpr int MD_W_BYTES = MD_W_DWORDS * 4;             // 101 376
-constexpr int MD_IMG_BYTES = 64 * MD_SLOTS;             // [64 rows][32 slots]: HIGH byte of the f16 multiplier (the low byte is 0)
+constexpr int MD_IMG_STRIDE = MD_SLOTS + 4;             // 36: rows 4 apart would share all their LDS banks at a stride of 32
+constexpr int MD_IMG_BYTES = 64 * MD_IMG_STRIDE;        // [64 rows][32 slots + pad]: HIGH byte of the f16 multiplier (the low byte is 0)
 constexpr int MD_MAP_BYTES = 64 * 16;                   // [run start lane][16]: feature index of a slot; a piece owns 16 per row
 constexpr int MD_VAL_BYTES = 64 * 4;
-constexpr int MD_WAVE_BYTES = MD_IMG_BYTES + MD_MAP_BYTES + MD_VAL_BYTES;       // 3 328
-constexpr int MD_LDS_TOTAL = MD_W_BYTES + N_HID * 4 + MD_WAVES * MD_WAVE_BYTES; // 141 824
+constexpr int MD_WAVE_BYTES = MD_IMG_BYTES + MD_MAP_BYTES + MD_VAL_BYTES;       // 3 584
+constexpr int MD_LDS_TOTAL = MD_W_BYTES + N_HID * 4 + MD_WAVES * MD_WAVE_BYTES; // 144 896
 constexpr int MD_MAX_ENTRIES = 16;                      // as DELTA_MAX: a legal turn changes at most 13 features
 
 // W table of the kernel: entry (f, unit) = -log2(e) · W1[unit][f] · s_f with s = 1 for the thermometer features, 1/2 for
@@ -119,6 +123,20 @@ __device__ __forceinline__ float md_half_sum(float x)
 }
 
 typedef _Float16 md_f16x8 __attribute__((ext_vector_type(8)));
+// diagnostic builds (tools/ab_build.sh x "-DBG_MD_PROF=k", tools/md_prof.py): the work counter then holds the shader cycles
+// the waves spent in phase k instead of the K-step count.  1 whole chunk loop, 2 rows -> masks, 3 unions, 4 image + map,
+// 5 pieces (product, sigmoids, W2 dot), 6 output sigmoid + arg-max, 7 weight staging
+#ifndef BG_MD_PROF
+#define BG_MD_PROF 0
+#endif
+// timing experiments (results are WRONG): 1 no union atomics, 2 no image / map writes, 4 no transcendentals, 8 no lane reduction,
+// 16 no B reads and MFMAs, 32 no per-game arg-max, 64 no pieces at all
+#ifndef BG_MD_ABL
+#define BG_MD_ABL 0
+#endif
+#define BG_MD_STAMP(K_BEGIN, K_END)                                                              \
+    if (BG_MD_PROF == (K_BEGIN)) prof_t0 = __builtin_readcyclecounter();                          \
+    if (BG_MD_PROF == (K_END)) n_work += (uint32_t)(__builtin_readcyclecounter() - prof_t0);
 typedef __attribute__((address_space(3))) uint32_t md_lds_u32;
 
 __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
@@ -129,6 +147,10 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
     unsigned long long *__restrict__ work_counter, unsigned long long *__restrict__ zero_words, int n_zero_words,
     unsigned long long *__restrict__ err_word, unsigned long long err_bit)
 {
+    uint32_t n_work = 0;                                  // K-steps x tiles executed by this wave (x 4 = MFMAs)
+    unsigned long long prof_t0 = 0;
+    (void)prof_t0;
+    BG_MD_STAMP(7, -1);
     // multi-step runs: the OTHER set of list counters is cleared here (see eval_rows_delta_kernel)
     if (zero_words && blockIdx.x == 0 && (int)threadIdx.x < n_zero_words) zero_words[threadIdx.x] = 0ull;
     extern __shared__ uint4 sMD[];
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
     const md_lds_u32 *sWl = (const md_lds_u32 *)sW;                         // the same, known to the compiler as LDS
     float *sW2 = reinterpret_cast<float *>(sW + MD_W_DWORDS);
     uint8_t *wave_lds = reinterpret_cast<uint8_t *>(sW2 + N_HID) + (threadIdx.x >> 6) * MD_WAVE_BYTES;
-    uint8_t *img = wave_lds;                                                // [64][32]
+    uint8_t *img = wave_lds;                                                // [64][36]
     uint8_t *fmap = wave_lds + MD_IMG_BYTES;                                // [64][16]
     float *vals = reinterpret_cast<float *>(wave_lds + MD_IMG_BYTES + MD_MAP_BYTES);
     for (int i = threadIdx.x; i < MD_W_BYTES / 16; i += MD_THREADS) sMD[i] = wm[i];
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
     __shared__ unsigned int s_ticket;
     if (threadIdx.x == 0) s_ticket = 0;
     __syncthreads();
+    BG_MD_STAMP(-1, 7);
 
     long long n_rows = n_rows_imm;
     if (n_rows_ptr) { const long long c = (long long)*n_rows_ptr; n_rows = c < n_rows_imm ? c : n_rows_imm; }
@@ -161,7 +184,6 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
     };
     const float b2 = *b2p;
     f32x2_t w2a = {sW2[n], sW2[32 + n]}, w2b = {sW2[64 + n], sW2[96 + n]};
-    uint32_t n_work = 0;                                  // K-steps x tiles executed by this wave (x 4 = MFMAs)
     bool bad_row = false;
 
     uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
@@ -173,7 +195,9 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
     }
     uint4 nr0 = root_rows[2 * (long long)nxi.x], nr1 = root_rows[2 * (long long)nxi.x + 1];
 
+    BG_MD_STAMP(1, -1);
     while (tile < n_tiles) {
+        BG_MD_STAMP(2, -1);
         const long long next_tile = grab();
         const long long row = tile * 64 + lane;
         const bool valid = row < n_rows;
@@ -187,12 +211,6 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
             const uint32_t q[8] = {r0.x & ~TURN_BIT, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pl[i] = valid ? p[i] : 0u; ql[i] = valid ? q[i] : 0u; }
-        }
-        {
-            const long long nrow = next_tile * 64 + lane;
-            nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0); nxi = make_uint2(0u, 0u);
-            if (next_tile < n_tiles && nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
-            nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1];
         }
         uint32_t cnt = 0;
 #pragma unroll
@@ -216,20 +234,47 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
             for (int i = 0; i < 8; ++i) M[i] = 0;
         }
 
+        BG_MD_STAMP(3, 2);
         // ---- pieces: runs of equal games.  Hmask bit i = lane i starts a run.
         const uint32_t prev_game = __shfl_up(game, 1, 64);
         unsigned long long hmask = __ballot(lane == 0 || prev_game != game);
-        uint32_t rs, U[8], pre[8], kc_total;
+        uint32_t rs, U[8], pre[8], R[8], kc_total;      // R = the union bits this lane enters into the slot -> feature map
         uint32_t *us = reinterpret_cast<uint32_t *>(img);                   // union words [64 run starts][8] alias the image
         uint4 *img4 = reinterpret_cast<uint4 *>(img);
         for (;;) {
             const unsigned long long below = hmask & (~0ull >> (63 - lane));
             rs = 63u - (uint32_t)__clzll(below);
+            const uint32_t dist = (uint32_t)lane - rs;
             img4[2 * lane] = make_uint4(0, 0, 0, 0); img4[2 * lane + 1] = make_uint4(0, 0, 0, 0);
+            // OR over the rows of (run, 16-lane row) up to this lane by four DPP steps -- same-address LDS atomics from
+            // every lane cost 15 us of the launch, one atomic per segment costs nothing
+            uint32_t X[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) X[w] = M[w];
+#define BG_MD_SCAN(D, CTRL)                                                                            \
+            {                                                                                            \
+                const uint32_t take = dist >= (uint32_t)(D) ? 0xFFFFFFFFu : 0u;                           \
+                _Pragma("unroll") for (int w = 0; w < 8; ++w)                                            \
+                    X[w] = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[w], CTRL, 0xF, 0xF, true) & take) | X[w]; \
+            }
+            BG_MD_SCAN(1, 0x111) BG_MD_SCAN(2, 0x112) BG_MD_SCAN(4, 0x114) BG_MD_SCAN(8, 0x118)
+#undef BG_MD_SCAN
+            // a feature is entered into the map by the first lane of the segment that has it (every row of a piece writing
+            // its features there: 13 lanes on one LDS byte)
+            {
+                const uint32_t take = dist >= 1u ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                    R[w] = M[w] & ~((uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[w], 0x111, 0xF, 0xF, true) & take);
+            }
+            const bool seg_last = (lane & 15) == 15 || ((hmask >> 1) >> lane) & 1ull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (BG_MD_ABL & 1) { for (int w = 0; w < 8; ++w) us[lane * 8 + w] = M[w]; }
+            else if (seg_last) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) atomicOr(&us[rs * 8 + w], M[w]);
+                for (int w = 0; w < 8; ++w) atomicOr(&us[rs * 8 + w], X[w]);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -252,27 +297,37 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
             if (cut == 0ull) { bad_row = true; break; }                     // cannot happen (a row holds <= 16 entries): never spin
             hmask |= cut;
         }
+        BG_MD_STAMP(4, 3);
         // ---- the image (zeroed: every slot a row does not touch multiplies by 0) and the slot -> feature map (zeroed: a K-step
         //      reads 8 slots whatever the union holds, and feature 0 is a finite W row)
         img4[2 * lane] = make_uint4(0, 0, 0, 0); img4[2 * lane + 1] = make_uint4(0, 0, 0, 0);
+        if (lane < MD_IMG_BYTES / 16 - 128) img4[128 + lane] = make_uint4(0, 0, 0, 0);
         reinterpret_cast<uint4 *>(fmap)[lane] = make_uint4(0, 0, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {
-            uint8_t *irow = img + lane * MD_SLOTS;
+            // (kc < MD_SLOTS and rs * 16 + kc < MD_MAP_BYTES hold by construction: a union has <= MD_SLOTS features, a row <=
+            //  MD_MAX_ENTRIES, a piece of R rows owns 16 R map bytes; a cut that failed above is the one exception, masked here)
+            uint8_t *irow = img + lane * MD_IMG_STRIDE;
             uint8_t *mrow = fmap + rs * 16;
+            uint8_t *dump = reinterpret_cast<uint8_t *>(vals + lane);      // (vals is written by the pieces below, read after them)
+            if (kc_total > (uint32_t)MD_SLOTS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) M[i] = 0;
+            }
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
                 const int sd = w >> 2, k = w & 3;
                 uint32_t x = M[w];
+                const uint32_t ng = ~G[w];
                 while (x) {
                     const int pos = __ffs(x) - 1;
                     x &= x - 1;
                     const uint32_t kc = pre[w] + (uint32_t)__popc(U[w] & ((1u << pos) - 1u));
                     uint32_t f, byte;
                     if (k < 3) {
-                        f = (uint32_t)(8 * (pos - 1) + 4 * sd + k);
-                        byte = ((G[w] >> pos) & 1u) ? 0x3Cu : 0xBCu;        // f16 +1 / -1
+                        f = (uint32_t)(8 * pos + (4 * sd + k - 8));
+                        byte = 0x3Cu | (((ng >> pos) & 1u) << 7);           // high byte of f16 +1 / -1
                     } else {
                         const Side sn{{pl[4 * sd], pl[4 * sd + 1], pl[4 * sd + 2], pl[4 * sd + 3]}};
                         const Side so{{ql[4 * sd], ql[4 * sd + 1], ql[4 * sd + 2], ql[4 * sd + 3]}};
@@ -284,10 +339,13 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
                         if (d > 8 || d < -8) { bad_row = true; d = 0; }     // no legal turn: the high byte alone would not hold it
                         byte = (uint32_t)f16_bits((_Float16)(float)d) >> 8;
                     }
-                    if (kc < (uint32_t)MD_SLOTS && rs * 16u + kc < (uint32_t)MD_MAP_BYTES) {
-                        irow[kc] = (uint8_t)byte;
-                        mrow[kc] = (uint8_t)f;
-                    }
+                    // the map byte goes to the map only from the lane that answers for the feature, else to a byte of its own
+                    uint8_t *mdst = ((R[w] >> pos) & 1u) ? mrow + kc : dump;
+                    if (BG_MD_ABL & 256) reinterpret_cast<volatile uint32_t *>(vals)[lane] = byte;     // a conflict-free dword instead
+                    else if (BG_MD_ABL & 512) irow[kc & 3] = (uint8_t)byte;                            // bytes, but the lane's own bank
+                    else if (!(BG_MD_ABL & 2)) irow[kc] = (uint8_t)byte;
+                    if (!(BG_MD_ABL & 128)) *mdst = (uint8_t)f;
+                    if (BG_MD_ABL & (2 | 128)) asm volatile("" :: "v"(byte), "v"(f), "v"(kc), "v"(mdst));
                 }
             }
         }
@@ -295,8 +353,9 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        BG_MD_STAMP(5, 4);
         // ---- piece by piece (wave-uniform): K-compacted product, hidden sigmoids, W2 dot
-        unsigned long long hm = hmask;
+        unsigned long long hm = (BG_MD_ABL & 64) ? 0ull : hmask;
         // the first piece's root term is requested here, every later one while the piece before it is computed
         float rq0, rq1, rq2, rq3;
         {
@@ -330,7 +389,7 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
                 const int nj = (rt + 1) >> 1;
                 int arow = t0 + rho;
                 arow = arow > 63 ? 63 : arow;                               // rows behind the piece: finite, never used
-                const uint32_t *ap = reinterpret_cast<const uint32_t *>(img + arow * MD_SLOTS + 4 * h);
+                const uint32_t *ap = reinterpret_cast<const uint32_t *>(img + arow * MD_IMG_STRIDE + 4 * h);
                 floatx16 acc0, acc1, acc2, acc3;
                 // one K-step: 8 features = 16 k-slots.  The B reads are volatile so that they stay sixteen ds_read_b32 into
                 // the operand registers themselves (merged into ds_read2_b32 they need a v_mov each to get there)
@@ -344,12 +403,18 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
                     a.u[3] = __builtin_amdgcn_perm(aw, aw, 0x030C030Cu);                                    \
                     _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                        \
                         const volatile md_lds_u32 *wr = sWl + ((mw >> (8 * m)) & 255u) * N_HID + n;         \
-                        bq0.u[m] = wr[0]; bq1.u[m] = wr[32]; bq2.u[m] = wr[64]; bq3.u[m] = wr[96];          \
+                        if (BG_MD_ABL & 16) { bq0.u[m] = bq1.u[m] = bq2.u[m] = bq3.u[m] = (uint32_t)(uintptr_t)wr; } else {   \
+                        bq0.u[m] = wr[0]; bq1.u[m] = wr[32]; bq2.u[m] = wr[64]; bq3.u[m] = wr[96]; }        \
                     }                                                                                      \
+                    if (BG_MD_ABL & 16) {                                                                   \
+                        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                    \
+                            acc0[q] = C0[q] + __builtin_bit_cast(float, a.u[q & 3] ^ bq0.u[q & 3]); acc1[q] = C1[q] + __builtin_bit_cast(float, bq1.u[q & 3]); \
+                            acc2[q] = C2[q] + __builtin_bit_cast(float, bq2.u[q & 3]); acc3[q] = C3[q] + __builtin_bit_cast(float, bq3.u[q & 3]); }            \
+                    } else {                                                                                \
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, bq0.v, C0, 0, 0, 0);                 \
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, bq1.v, C1, 0, 0, 0);                 \
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, bq2.v, C2, 0, 0, 0);                 \
-                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, bq3.v, C3, 0, 0, 0);                 \
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, bq3.v, C3, 0, 0, 0); }               \
                 }
                 {
                     const floatx16 zero = {0};
@@ -357,27 +422,38 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
                 }
                 for (int s = 1; s < nst; ++s) BG_MD_KSTEP(s, acc0, acc1, acc2, acc3);
 #undef BG_MD_KSTEP
-                n_work += (uint32_t)nst;
+                if (BG_MD_PROF == 0) n_work += (uint32_t)nst;
                 // hidden sigmoids and the W2 dot of four accumulator registers (= eight rows) at a time; the sums over the 32
                 // lanes of a half are taken by a reduce-scatter: lane l ends with the total of register 4 G + (l & 3)
                 float outv = 0.0f;
+#if BG_MD_ABL & 4
+#define BG_MD_EXP(X) ((X) * 0.75f)
+#define BG_MD_RCP(X) ((X) * 0.5f)
+#else
+#define BG_MD_EXP(X) __builtin_amdgcn_exp2f(X)
+#define BG_MD_RCP(X) __builtin_amdgcn_rcpf(X)
+#endif
 #define BG_MD_ROWSUM(J)                                                                                    \
                 ({                                                                                          \
-                    f32x2_t e0 = {__builtin_amdgcn_exp2f(acc0[J]), __builtin_amdgcn_exp2f(acc1[J])};         \
-                    f32x2_t e1 = {__builtin_amdgcn_exp2f(acc2[J]), __builtin_amdgcn_exp2f(acc3[J])};         \
+                    f32x2_t e0 = {BG_MD_EXP(acc0[J]), BG_MD_EXP(acc1[J])};                                   \
+                    f32x2_t e1 = {BG_MD_EXP(acc2[J]), BG_MD_EXP(acc3[J])};                                   \
                     e0 = __builtin_elementwise_fma(e0, ea, (f32x2_t){1.0f, 1.0f});                           \
                     e1 = __builtin_elementwise_fma(e1, eb, (f32x2_t){1.0f, 1.0f});                           \
-                    const f32x2_t q0 = {__builtin_amdgcn_rcpf(e0.x), __builtin_amdgcn_rcpf(e0.y)};           \
-                    const f32x2_t q1 = {__builtin_amdgcn_rcpf(e1.x), __builtin_amdgcn_rcpf(e1.y)};           \
+                    const f32x2_t q0 = {BG_MD_RCP(e0.x), BG_MD_RCP(e0.y)};                                   \
+                    const f32x2_t q1 = {BG_MD_RCP(e1.x), BG_MD_RCP(e1.y)};                                   \
                     f32x2_t ps = q0 * w2a;                                                                  \
                     ps = __builtin_elementwise_fma(q1, w2b, ps);                                            \
                     ps.x + ps.y;                                                                            \
                 })
 #pragma unroll
                 for (int G4 = 0; G4 < 4; ++G4) {
-                    if (4 * G4 < nj) {                                      // wave-uniform
+                    if (4 * G4 < nj) {                                      // wave-uniform, like the four tests below
+                        // two registers at a time: their transcendental chains fill each other's wait states (a register
+                        // behind the piece's last holds finite values of rows that are never stored)
                         const float p0 = BG_MD_ROWSUM(4 * G4), p1 = BG_MD_ROWSUM(4 * G4 + 1);
-                        const float p2 = BG_MD_ROWSUM(4 * G4 + 2), p3 = BG_MD_ROWSUM(4 * G4 + 3);
+                        float p2 = 0.0f, p3 = 0.0f;
+                        if (4 * G4 + 2 < nj) { p2 = BG_MD_ROWSUM(4 * G4 + 2); p3 = BG_MD_ROWSUM(4 * G4 + 3); }
+                        if (BG_MD_ABL & 8) { outv = ((n >> 2) == G4) ? (p0 + p1) + (p2 + p3) : outv; continue; }
                         const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
                         const float x = (b0 ? p1 : p0) + md_dpp<0xB1, 0xF>(b0 ? p0 : p1);      // + lane ^ 1
                         const float y = (b0 ? p3 : p2) + md_dpp<0xB1, 0xF>(b0 ? p2 : p3);
@@ -397,15 +473,26 @@ __global__ __launch_bounds__(MD_THREADS) void eval_rows_mdelta_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        BG_MD_STAMP(6, 5);
+        // the next chunk's rows are requested only now: held across the pieces above they cost the 18 registers that decide
+        // between three and four waves per SIMD
+        {
+            const long long nrow = next_tile * 64 + lane;
+            nx0 = make_uint4(0, 0, 0, 0); nx1 = make_uint4(0, 0, 0, 0); nxi = make_uint2(0u, 0u);
+            if (next_tile < n_tiles && nrow < n_rows) { nx0 = rows[2 * nrow]; nx1 = rows[2 * nrow + 1]; nxi = info[nrow]; }
+        }
         {
             const float sum = valid ? vals[lane] : 0.0f;
             const float v = fast_sigmoid(sum + b2);
             if (valid) values[row] = v;
-            best_atomic_max(best, inf.x, v, inf.y, valid, 64);
+            if (!(BG_MD_ABL & 32)) best_atomic_max(best, inf.x, v, inf.y, valid, 64);
         }
+        nr0 = root_rows[2 * (long long)nxi.x]; nr1 = root_rows[2 * (long long)nxi.x + 1];
         __builtin_amdgcn_wave_barrier();
+        BG_MD_STAMP(-1, 6);
         tile = next_tile;
     }
+    BG_MD_STAMP(-1, 1);
     __shared__ unsigned int s_nw;
     if (threadIdx.x == 0) s_nw = 0;
     __syncthreads();

@@ -619,7 +619,7 @@ struct bgamd_env {
     float4 *d_wt[2] = {nullptr, nullptr};  // W1^T [198][132] for the incremental evaluator
     uint4 *d_wm[2] = {nullptr, nullptr};   // W1^T as f16 hi | lo dwords [198][4][32] for the MFMA delta kernel (bg_eval_mfma.h)
     bool wm_ok[2] = {false, false};        // the slot's table fits f16 (else the VALU delta kernel evaluates that slot)
-    bool mfma_delta = true;                // BGAMD_VALU_DELTA=1: round 2's eval_rows_delta_kernel instead
+    bool mfma_delta = false;               // BGAMD_MFMA_DELTA=1: eval_rows_mdelta_kernel instead of eval_rows_delta_kernel
     uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term)
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
@@ -751,7 +751,9 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
-    env->mfma_delta = getenv("BGAMD_VALU_DELTA") == nullptr;
+    // round 3's K-compacted MFMA delta kernel (bg_eval_mfma.h) is correct and canonical but measured 10 % slower than the VALU
+    // kernel on the same box: opt-in
+    env->mfma_delta = getenv("BGAMD_MFMA_DELTA") != nullptr && atoi(getenv("BGAMD_MFMA_DELTA")) != 0;
     // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
     // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
@@ -880,6 +882,15 @@ int bgamd_env_reset_episode(bgamd_env *env, uint32_t episode, void *stream)
     hipLaunchKernelGGL(reset_kernel, grid1(env->v.n, 256), dim3(256), 0, (hipStream_t)stream, env->v, (const int32_t *)nullptr, episode);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
+}
+
+int bgamd_env_reseed(bgamd_env *env, uint64_t seed, uint64_t lane_offset, uint64_t lane_stride, void *stream)
+{
+    ENV_GUARD(env);
+    env->v.seed = seed;
+    env->v.lane_offset = lane_offset;
+    env->v.lane_stride = lane_stride ? lane_stride : (uint64_t)env->v.n;
+    return bgamd_env_reset_episode(env, 0u, stream);
 }
 
 int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask, void *stream)
@@ -1549,6 +1560,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
                        sv.root_hidden);
     long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;
     dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
+    KTimer t(env, s, 1);
     if (env->mfma_delta && env->wm_ok[slot])
         hipLaunchKernelGGL(eval_rows_mdelta_kernel, dim3((unsigned)dblocks), dim3(MD_THREADS), MD_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
                            (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const uint4 *)env->d_wm[slot],

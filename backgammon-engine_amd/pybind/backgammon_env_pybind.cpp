@@ -67,7 +67,7 @@ public:
         if (!g_pool.empty()) {
             env = g_pool.back();
             g_pool.pop_back();
-            check(bgamd_env_reset_episode(env, (uint32_t)(g_next_id + 1), nullptr), "reset_episode");
+            check(bgamd_env_reseed(env, g_seed, g_next_id, 1ull << 40, nullptr), "reseed");   // the dice a new env would roll
             check(bgamd_env_reset_stats(env, nullptr), "reset_stats");
         } else
             check(bgamd_env_create(&env, 1, 0, g_seed, g_next_id, 1ull << 40, 32768), "bgamd_env_create");

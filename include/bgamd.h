@@ -91,6 +91,11 @@ int bgamd_env_reset(bgamd_env *env, void *stream);
  * loop that plays one game per lane and round gives every round fresh dice this way -- play_game draws new dice for
  * every game (train.py:64-121, 527-547).  Counters are kept. */
 int bgamd_env_reset_episode(bgamd_env *env, uint32_t episode, void *stream);
+/* Gives an existing env the dice streams a freshly created one would have (seed, lane_offset, lane_stride as in
+ * bgamd_env_create; lane_stride 0 = n_games) and resets it to episode 0.  Pooled one-lane envs of the scalar Game surface
+ * (the reference constructs a Game per candidate, game.cpp:68-77) are re-seeded with it, so set_seed() decides the dice of
+ * every Game created afterwards whether its env is new or comes from the pool. */
+int bgamd_env_reseed(bgamd_env *env, uint64_t seed, uint64_t lane_offset, uint64_t lane_stride, void *stream);
 /* Only the lanes with d_mask[g] != 0 restart, as the next episode of that lane (start position, opening roll of
  * the next global game id) -- what BGAMD_AUTO_RESET does for a finished game, on demand. */
 int bgamd_env_reset_lanes(bgamd_env *env, const int32_t *d_mask /*[n]*/, void *stream);

@@ -8,6 +8,9 @@ TAG=${1:?tag, e.g. r02_v1}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# build before profiling: a rocprofv3-preloaded process has the GPU initialised before main() and must not spawn compilers
+python3 -c "import __graft_entry__ as g; g.build()" > /dev/null
+export BGAMD_NO_BUILD=1
 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py > "$OUT/bench_under_rocprof.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
-# quick same-box A/B of the value-net stage: the library as built vs BGAMD_VALU_DELTA=1 (round 2's kernel), interleaved
+# quick same-box A/B of the value-net stage: BGAMD_MFMA_DELTA=1 (round 3's MFMA delta kernel) vs the default (round 2's VALU kernel), interleaved
 # usage (on the GPU box): bash tools/quick_ab.sh TAG [rounds]
 TAG=${1:?tag}; R=${2:-2}
 mkdir -p gpurun_out/$TAG
 for i in $(seq 1 $R); do
-  python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/mfma_$i.json
-  BGAMD_VALU_DELTA=1 python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/valu_$i.json
+  BGAMD_MFMA_DELTA=1 python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/mfma_$i.json
+  python bench.py --quick 2>/dev/null | tail -1 > gpurun_out/$TAG/valu_$i.json
 done
 python - <<PY
 import json,glob
