@@ -12,8 +12,12 @@ MARKER = b"BGAMD_SRC_HASH="
 
 
 def source_files():
+    """The tracked sources of the library and nothing else: csrc/*.h, csrc/*.hip and the ABI header.  (Compiler temporaries such
+    as csrc/*.hipfb are git-ignored but may sit in the directory: a digest that took them in could not be reproduced from a
+    checkout of the commit -- tests/test_abi_cpu.py checks exactly that against `git archive HEAD`.)"""
     csrc = os.path.join(PKG, "csrc")
-    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))] + [os.path.join(ROOT, "include", "bgamd.h")]
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")))
+    return [os.path.join(csrc, f) for f in names] + [os.path.join(ROOT, "include", "bgamd.h")]
 
 
 def source_hash() -> str:

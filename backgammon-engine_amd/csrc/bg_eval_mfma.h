@@ -7,7 +7,7 @@
 // ids inside a 64-row chunk) share one K-compacted product on v_mfma_f32_32x32x16_f16:
 //
 //     D[rows x Kc] · Wc[Kc x 128],   Kc = the UNION of the features any row of the piece changes (measured: mean 14.6 per
-//                                     game, p99 34, with the reference checkpoint's greedy play; oracle, 3 868 turns)
+//                                     game, p99 34, over 3 868 turns of the reference checkpoint's greedy play: DESIGN.md §4)
 //
 //   * K-compaction: the eight difference masks of a row (three thermometer levels + the (n-3)/2 feature per side, bar and
 //     borne-off bits riding in the fourth word) are OR-ed over the piece; a feature's slot is its rank in that union

@@ -56,11 +56,13 @@ enum {
     BGAMD_WEIGHTS_SLOT1 = 64  /* greedy step evaluates with weight slot 1 instead of slot 0        */
 };
 
-/* value-net arithmetic.  F32: fp32 FMAs throughout.  In a greedy step the hidden layer is evaluated INCREMENTALLY:
- * one dense v_mfma_f32_32x32x2_f32 pass per game for the root position, then  a_row = a_root + Σ Δx_f · W1[:, f]
- * over the few features an afterstate changes (same real sum as the dense chain, different association, values
- * agree to ~1e-7; the root pass uses the exact bf16 x 3 split of W1 on v_mfma_f32_32x32x16_bf16, or the f32 MFMA
- * chain when BGAMD_ROOT_F32=1 is in the environment at env creation).  F32_DENSE: the dense MFMA chain over every afterstate (what bgamd_evaluate always uses).  F16X2: W1 split into f16 hi + lo
+/* value-net arithmetic.  F32: fp32-grade values (inside the 1e-5 parity bound, measured 1.8e-7).  In a greedy step the
+ * hidden layer is evaluated INCREMENTALLY: one dense pass per game for the root position (W1 split exactly into three
+ * bf16 terms on v_mfma_f32_32x32x16_bf16, fp32 accumulation; BGAMD_ROOT_F32=1 at env creation: the f32 MFMA chain
+ * v_mfma_f32_32x32x2_f32 instead), then  a_row = a_root + Σ Δx_f · W1[:, f]  in fp32 FMAs over the few features an
+ * afterstate changes (same real sum as the dense chain, different association, values agree to ~1e-7).
+ * BGAMD_MFMA_DELTA=1 at env creation: that sum on v_mfma_f32_32x32x16_f16 over a K-compacted fixed-point W table
+ * instead (csrc/bg_eval_mfma.h: exact sums, values within 1.4e-6; measured slower, opt-in).  F32_DENSE: the dense MFMA chain over every afterstate (what bgamd_evaluate always uses).  F16X2: W1 split into f16 hi + lo
  * (22 mantissa bits), exact products, fp32 accumulation on v_mfma_f32_32x32x16_f16 -- fp32-grade values (inside
  * the 1e-5 parity bound) on the fast matrix pipe.  BF16: single bf16 weights, speed mode outside the bound. */
 enum { BGAMD_F32 = 0, BGAMD_BF16 = 1, BGAMD_F16X2 = 2, BGAMD_F32_DENSE = 3 };

@@ -41,6 +41,7 @@ def main():
     tenv.load_weights(w)
     L = DeviceTDLambdaLearner(w, max_games=train_lanes, alpha=0.1, lam=0.9)
     sq = cnt = 0
+    r0 = {}
     for rnd in range(3):                                 # three rounds: each plays with the weights the one before left
         rows, lengths, p1_won = play_round(tenv, max_plies=400, epsilon=0.05)
         # round 0: the whole shard lock-step; round 1: sub-rounds of 256 games per rank (every rank runs the same number);
@@ -49,10 +50,13 @@ def main():
         a, b = L.replay_rows(rows, lengths, p1_won, group=dist.group.WORLD, sub_round=sub, slots=slots,
                              batch_scale=24.0 / (world * (sub or slots or train_lanes)))
         sq, cnt = sq + a, cnt + b
+        if rnd == 0:                                     # the lock-step round's log and result: the parent replays both shards' logs on ONE learner
+            r0 = dict(r0_rows=rows.cpu().numpy(), r0_lengths=lengths.cpu().numpy(), r0_p1_won=p1_won.cpu().numpy(),
+                      r0_theta=L.theta.cpu().numpy())
         tenv.load_weights(L.theta.cpu().numpy())
     np.savez(os.path.join(out, f"rank{rank}.npz"), states=st, turns=tn, theta=L.theta.cpu().numpy(),
              totals=np.array([tot["steps"], tot["games_finished"], tot["p1_wins"]], dtype=np.int64),
-             learner=np.array([sq, cnt], dtype=np.float64), lengths=lengths.cpu().numpy())
+             learner=np.array([sq, cnt], dtype=np.float64), lengths=lengths.cpu().numpy(), **r0)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -74,6 +74,36 @@ def test_library_carries_the_digest_of_its_sources(built):
     assert built.load().bgamd_source_hash().decode() == want == built.source_hash()
 
 
+def test_digest_is_reproducible_from_the_commit(built, tmp_path):
+    """The digest a library carries must be reproducible from a checkout of the commit it was built from: every file that
+    enters it is tracked by git (round 2 hashed a git-ignored compiler temporary that happened to sit in csrc/), and the
+    digest of `git archive HEAD` equals source_hash() whenever the hashed files have no uncommitted changes."""
+    import hashlib
+    import subprocess
+    import tarfile
+    from backgammon_env import _srchash
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout (gpurun snapshots travel without .git)")
+    files = _srchash.source_files()
+    rel = [os.path.relpath(f, ROOT) for f in files]
+    assert all(f.endswith((".h", ".hip")) for f in rel)
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "--error-unmatch"] + rel, capture_output=True, text=True)
+    assert tracked.returncode == 0, "hashed but untracked: " + tracked.stderr
+    listed = set(subprocess.check_output(["git", "-C", ROOT, "ls-files", "backgammon-engine_amd/csrc"], text=True).split())
+    assert {r for r in rel if r.startswith("backgammon-engine_amd/csrc")} == {l for l in listed if l.endswith((".h", ".hip"))}
+    if subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--"] + rel).returncode != 0:
+        pytest.skip("hashed sources have uncommitted changes: the commit's digest is another one")
+    tar = tmp_path / "head.tar"
+    subprocess.check_call(["git", "-C", ROOT, "archive", "-o", str(tar), "HEAD"] + rel)
+    with tarfile.open(tar) as t:
+        t.extractall(tmp_path / "head")
+    h = hashlib.sha256()
+    for r in rel:                                              # the digest of _srchash.source_hash(), over the archived files
+        h.update(os.path.basename(r).encode() + b"\0")
+        h.update((tmp_path / "head" / r).read_bytes())
+    assert h.hexdigest()[:16] == _srchash.source_hash()
+
+
 def test_checkpoint_interop_against_the_reference(built):
     """SURVEY §8f row 2.  tests/golden/f2_interop.json was written in the build container by make_golden_r2.py with the
     UNMODIFIED reference: its checkpoint through this repo's loader, and a state_dict written by this repo's learner

@@ -37,6 +37,22 @@ def O():
     return oracle
 
 
+def _state_from_features(x):
+    """198 encoder features (model.py:111-144) -> (state28 int32, turn): thermometer counts back to checker counts."""
+    s = np.zeros(28, dtype=np.int32)
+    for i in range(24):
+        for side, sgn in ((0, 1), (1, -1)):
+            f = x[8 * i + 4 * side: 8 * i + 4 * side + 4]
+            n = int(round(float(f[0] + f[1] + f[2] + 2.0 * f[3])))
+            if n:
+                assert s[i] == 0
+                s[i] = sgn * n
+    s[24], s[25] = int(round(2 * float(x[194]))), int(round(2 * float(x[195])))
+    s[26], s[27] = int(round(15 * float(x[196]))), int(round(15 * float(x[197])))
+    assert abs(s[:24][s[:24] > 0].sum() + s[24] + s[26] - 15) == 0 and abs(-s[:24][s[:24] < 0].sum() + s[25] + s[27] - 15) == 0
+    return s, (0 if x[192] == 1.0 else 1)
+
+
 def _rows_by_state(states):
     return {tuple(int(v) for v in s): i for i, s in enumerate(states)}
 
@@ -343,17 +359,24 @@ def test_config5_share_bf16_selfplay_fp32_traces_32768(bg, O, weights):
     assert env.stats()["error_flags"] == 0 and (ln > 0).mean() > 0.995
     # sampled lanes: each logged transition s_t -> s_{t+1} is one of the oracle's afterstates of s_t (with the turn flipped)
     S = _np(env.encode_rows(rows[:12, :4096:97].contiguous()))      # [12, 43, 198]
-    dice_ok = 0
+    legal = 0
     lanes = list(range(0, 4096, 97))
+    rolls = [(a, b) for a in range(1, 7) for b in range(a, 7)]
     for j, lane in enumerate(lanes):
         for t in range(10):
             if t + 1 >= ln[lane]:
                 break
-            x0, x1 = S[t, j], S[t + 1, j]
-            tb = 0 if x0[192] == 1.0 else 1
-            assert x1[192 + (1 - tb)] == 1.0                   # the turn flipped
-            dice_ok += 1
-    assert dice_ok > 300
+            (s0, tb), (s1, tb1) = _state_from_features(S[t, j]), _state_from_features(S[t + 1, j])
+            assert tb1 == 1 - tb                               # the turn flipped
+            ok = False
+            for d1, d2 in rolls:                               # the dice are not logged: some roll must explain the move
+                cand = O.evaluate_turn_sequences(O.State.from28(s0, tb), tb, d1, d2)[2]
+                if (len(cand) == 0 and (s1 == s0).all()) or (len(cand) and (cand == s1[None, :]).all(axis=1).any()):
+                    ok = True
+                    break
+            assert ok, (lane, t, s0.tolist(), s1.tolist())
+            legal += 1
+    assert legal > 300
     # agreement of the bf16 choices with fp32 on the same positions (one step from a common mid-game state)
     a, b = bg.VecGame(8192, seed=99), bg.VecGame(8192, seed=99)
     a.load_weights(weights); b.load_weights(weights)
@@ -432,6 +455,25 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
     assert np.abs(r[0]["theta"] - weights).max() > 1e-4
     assert not np.array_equal(r[0]["lengths"], r[1]["lengths"])   # the two shards played different games
     assert r[0]["learner"][1] > 0 and r[1]["learner"][1] > 0
+    # sharded == unsharded for the DEVICE learner on the lock-step route: both shards' round-0 logs replayed by ONE learner
+    # (2 048 games, the same per-game step) give the weights the two all-reducing replicas ended round 0 with, to fp32
+    # rounding -- the sum over the games is associated differently, nothing else
+    from backgammon_env.learner import DeviceTDLambdaLearner
+    assert np.array_equal(r[0]["r0_theta"], r[1]["r0_theta"])
+    T = max(r[0]["r0_rows"].shape[0], r[1]["r0_rows"].shape[0])
+    rows_all = np.zeros((T, 2 * train_lanes, 8), dtype=np.int32)
+    for k in range(2):
+        rows_all[:r[k]["r0_rows"].shape[0], k * train_lanes:(k + 1) * train_lanes] = r[k]["r0_rows"]
+    lengths_all = np.concatenate([r[0]["r0_lengths"], r[1]["r0_lengths"]])
+    p1_all = np.concatenate([r[0]["r0_p1_won"], r[1]["r0_p1_won"]])
+    one = DeviceTDLambdaLearner(weights, max_games=2 * train_lanes, alpha=0.1, lam=0.9)
+    one.replay_rows(torch.from_numpy(rows_all).cuda(), torch.from_numpy(lengths_all).cuda(), torch.from_numpy(p1_all).cuda(),
+                    batch_scale=24.0 / (2 * train_lanes))
+    th_one = _np(one.theta)
+    moved = np.abs(th_one - weights).max()
+    gap = np.abs(th_one - r[0]["r0_theta"]).max()
+    print("device learner, lock-step round: 2 all-reducing shards vs one learner over both logs: max |dtheta| %.3g (weights moved %.3g)" % (gap, moved))
+    assert moved > 1e-4 and gap < 2e-5 * max(1.0, moved) and gap < 0.02 * moved
 
 
 # ---- the scalar drop-in surface: whole games in the shape of the reference's loop ------------------------------------------
