@@ -21,6 +21,7 @@
 #include "bg_board.h"
 #include "bg_eval.h"
 #include "bg_eval_mfma.h"
+#include "bg_eval_dense16.h"
 #include "bg_learner.h"
 #include "bg_schedule.h"
 #include "bg_movegen.h"
@@ -624,6 +625,8 @@ struct bgamd_env {
     uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term)
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
+    uint4 *d_wd16[2] = {nullptr, nullptr}; // the same split with -log2(e) and b1 folded in: the register-resident dense kernel (bg_eval_dense16.h)
+    bool d16 = false;                      // BGAMD_F16X2_RESIDENT=1: eval_rows_d16_kernel (W1 resident in registers) for BGAMD_F16X2 -- measured 6 % slower than round 1's eval_rows_f16x2_kernel
     uint2 *d_lut = nullptr;                // count -> 4 bf16 features
     uint2 *d_lut16 = nullptr;              // count -> 4 f16 features
     bool has_weights[2] = {false, false};
@@ -755,6 +758,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     // round 3's K-compacted MFMA delta kernel (bg_eval_mfma.h) is correct and canonical but measured 10 % slower than the VALU
     // kernel on the same box: opt-in
     env->mfma_delta = getenv("BGAMD_MFMA_DELTA") != nullptr && atoi(getenv("BGAMD_MFMA_DELTA")) != 0;
+    env->d16 = getenv("BGAMD_F16X2_RESIDENT") != nullptr && atoi(getenv("BGAMD_F16X2_RESIDENT")) != 0;
     // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
     // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
@@ -801,6 +805,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&env->d_wl3[k], 3 * EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
+        HIPCHK(hipMalloc(&env->d_wd16[k], EVAL16X2_W_BYTES));
     }
     HIPCHK(hipMalloc(&env->d_lut16, EVAL16_LUT_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16X2_LDS_TOTAL));
@@ -851,7 +856,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_wd16[0], env->d_wd16[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     if (env->d_scalar) hipFree(env->d_scalar);
@@ -1187,6 +1192,8 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     relayout_w1_f16x2(h_weights, wx2.data());
     make_count_lut_f16(lut);
     HIPCHK(hipMemcpy(env->d_wlx2[slot], wx2.data(), EVAL16X2_W_BYTES, hipMemcpyHostToDevice));
+    relayout_w1_d16(h_weights, wx2.data());
+    HIPCHK(hipMemcpy(env->d_wd16[slot], wx2.data(), EVAL16X2_W_BYTES, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(env->d_lut16, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
     env->has_weights[slot] = true;
     return BGAMD_OK;
@@ -1205,7 +1212,16 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
     long long eb = (est_rows + (EVAL_THREADS / 64) * 32 - 1) / ((EVAL_THREADS / 64) * 32);
     eb = eb < 1 ? 1 : (eb > env->n_cu ? env->n_cu : eb);
     const dim3 egrid((unsigned)eb);
-    if (precision == BGAMD_F16X2) {
+    if (precision == BGAMD_F16X2 && env->d16) {
+        KTimer t(env, s, 1);
+        long long tiles = (est_rows + 31) / 32;
+        const long long per_cu = BG_D16_WAVES;                                                     // 4-wave workgroups per CU
+        long long wg = tiles < 1 ? 1 : (tiles > per_cu * env->n_cu ? per_cu * env->n_cu : tiles);
+        hipLaunchKernelGGL(eval_rows_d16_kernel<2>, dim3((unsigned)wg), dim3(D16_THREADS), D16_LDS_BYTES, s, rows, n_rows_ptr,
+                           n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
+                           (const uint4 *)env->d_wd16[slot], (const uint2 *)env->d_lut16, w2, b2, values, info, best,
+                           n_rows_ptr ? &env->v.counters[C_KSTEPS] : (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0);
+    } else if (precision == BGAMD_F16X2) {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f16x2_kernel, egrid, dim3(EVAL_THREADS), EVAL16X2_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
