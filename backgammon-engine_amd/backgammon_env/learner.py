@@ -14,6 +14,8 @@ from the reference, which replays games one after another.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -88,7 +90,10 @@ class TDLambdaLearner:
         eW1, eb1, eW2, eb2 = self._split(e)
         sq = torch.zeros((), dtype=torch.float64, device=dev)
         cnt = torch.zeros((), dtype=torch.int64, device=dev)
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # BGAMD_FORCE_COLLECTIVE=1: issue the per-step all-reduce on a group of ONE rank too (tools/train_dist_step.py measures what the
+        # collective's launch costs a training step with the RCCL communicator present; more ranks are the driver's to launch)
+        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
+                                                                         os.environ.get("BGAMD_FORCE_COLLECTIVE") == "1")
         n_steps = torch.tensor([min(T, int(lengths.max().item()) if G else 0)], dtype=torch.int64, device=dev)
         if distributed:                      # every rank must issue the same number of all-reduces
             dist.all_reduce(n_steps, op=dist.ReduceOp.MAX, group=group)
@@ -276,7 +281,10 @@ class DeviceTDLambdaLearner:
             raise ValueError("a game is longer than the trajectory log")
         sl, order = torch.sort(lengths, descending=True, stable=True)
         n_games = int((sl > 0).sum().item())
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # BGAMD_FORCE_COLLECTIVE=1: issue the per-step all-reduce on a group of ONE rank too (tools/train_dist_step.py measures what the
+        # collective's launch costs a training step with the RCCL communicator present; more ranks are the driver's to launch)
+        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
+                                                                         os.environ.get("BGAMD_FORCE_COLLECTIVE") == "1")
         if slots and slots > 0:
             return self._replay_stream(rows, T, n, lengths, won, order[:n_games], sl[:n_games], int(slots), group, distributed,
                                        batch_scale, split_apply)

@@ -868,29 +868,184 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_wide_kernel(TdView v
             *reinterpret_cast<td_f32x4 *>(v.partial + (long long)blockIdx.x * TD_LD + (k * TD_WIDE_THREADS + tid) * 4) = acc[k];
 }
 
-// block 256 = 64 parameters x 4 group lanes.  upd (optional) receives the summed update; apply adds it to theta
+// A 16-byte store that is written through to the memory side (sc1) instead of staying dirty in the XCD's L2 until the kernel ends:
+// a step's trace pass leaves ~54 MB dirty (26 MB of partial sums + the written trace columns), and the write-back of dirty lines at
+// the kernel boundary is serial time (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s).  BG_TD_WT=0: plain stores.
+#ifndef BG_TD_WT
+#define BG_TD_WT 1
+#endif
+__device__ __forceinline__ void td_store_wt(td_f32x4 *p, td_f32x4 x)
+{
+#if BG_TD_WT
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+#else
+    *p = x;
+#endif
+}
+
+// The whole-row pass for MID-SIZED steps (a streamed replay through 1 024 .. 8 191 slots: what configs 4 / 5 run at the batch
+// sizes the quality study allows), software-pipelined.  Such a step has one chunk of TD_CHUNK games per CU; td_trace_wide_kernel
+// walks it in rounds of two games -- masks, loads, WAIT, arithmetic, stores -- and the rounds' latencies add up (26.7 us per step
+// at 2 048 slots for 104 MB that sit in the Infinity Cache).  Here a workgroup has the CU to itself (8 waves, up to 256 VGPRs):
+// the loads of game q + 1 (13 float4 per thread, its active columns among them) go out BEFORE game q is computed and stored, into
+// a second register set.  Thread mapping, arithmetic and the order of the partial sums are td_trace_wide_kernel's: same bits.
+template <bool FIRST>
+__global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v, long long n_active, float emul, float ginv, float cmul, int full)
+{
+    static_assert(TD_WIDE_THREADS == 512, "the pipelined pass is written for 512-thread workgroups");
+    __shared__ __attribute__((aligned(16))) float fs[TD_CHUNK][TD_FLD];
+    __shared__ float cs[TD_CHUNK];
+    __shared__ uint32_t ms[TD_CHUNK][TD_MASK_WORDS], ns[TD_CHUNK][TD_MASK_WORDS];
+    const int tid = threadIdx.x;
+    const int c = tid >> 5;
+    const int n0 = (tid & 31) * 4;
+    const int base = 4 * ((c >> 2) & 1), level = c & 3;
+    const int pos0 = (c >> 3) + 1;
+    const bool t_w1 = tid < 192, t_in = tid < 272;
+    int ia[4];
+    float xfix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = (TD_WIDE_KL * TD_WIDE_THREADS + tid) * 4 + u;
+        xfix[u] = 1.0f;
+        if (p < TD_OFF_B1) ia[u] = TD_F_DB1 + (p & (N_HID - 1));
+        else if (p < TD_OFF_W2) ia[u] = TD_F_DB1 + (p - TD_OFF_B1);
+        else if (p < TD_OFF_B2) ia[u] = TD_F_GH + (p - TD_OFF_W2);
+        else if (p == TD_OFF_B2) ia[u] = TD_F_G;
+        else { ia[u] = TD_F_G; xfix[u] = 0.0f; }
+    }
+    td_f32x4 acc[TD_WIDE_K];
+#pragma unroll
+    for (int k = 0; k < TD_WIDE_K; ++k) acc[k] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long long chunk = blockIdx.x; chunk * TD_CHUNK < n_active; chunk += gridDim.x) {
+        const long long gb = chunk * TD_CHUNK;
+        const long long left = n_active - gb;
+        const int m = left < TD_CHUNK ? (int)left : TD_CHUNK;
+        __syncthreads();
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(v.fac + gb * TD_FLD);
+            float4 *dst = reinterpret_cast<float4 *>(&fs[0][0]);
+            for (int q = tid; q < m * (TD_FLD / 4); q += TD_WIDE_THREADS) dst[q] = src[q];
+            if (tid < m) cs[tid] = v.coef[gb + tid] * cmul;
+            if (tid < m * TD_MASK_WORDS) {
+                (&ms[0][0])[tid] = v.amask[gb * TD_MASK_WORDS + tid];
+                (&ns[0][0])[tid] = v.anew[gb * TD_MASK_WORDS + tid];
+            }
+        }
+        __syncthreads();
+        // which of the thread's 13 positions exist in game q (act) and have to be read (rd), and the reads themselves
+        auto issue = [&](int q, uint32_t &act, uint32_t &rd, td_f32x4 (&ev)[TD_WIDE_K]) {
+            act = 0; rd = 0;
+            if (q < m) {
+#pragma unroll
+                for (int k = 0; k < TD_WIDE_K; ++k) {
+                    const int sh = ((TD_WIDE_CPG * k) & 31) + c;
+                    bool a, fresh;
+                    if (k < TD_WIDE_KL || t_w1) {
+                        a = (ms[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u;
+                        fresh = FIRST || ((ns[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u);
+                    } else { a = t_in && (ms[q][TD_FLAG_WORD] & 1u); fresh = FIRST || (ns[q][TD_FLAG_WORD] & 1u); }
+                    act |= (a ? 1u : 0u) << k;
+                    rd |= ((a && !fresh) ? 1u : 0u) << k;
+                }
+            }
+            // EVERY one of the 13 loads is issued -- a position that is not read fetches one shared dummy line instead -- so that the
+            // number of loads in flight is static and the wait before game q's arithmetic is a counted vmcnt that leaves game q + 1's
+            // loads in flight (conditional loads made the compiler wait for vmcnt(0): no pipelining at all)
+            const float *eg = v.e + (gb + (q < m ? q : 0)) * TD_LD + tid * 4;
+            const float *dummy = v.partial;
+#pragma unroll
+            for (int k = 0; k < TD_WIDE_K; ++k) {
+                const float *src = ((rd >> k) & 1u) ? eg + k * (TD_WIDE_THREADS * 4) : dummy;
+                ev[k] = *reinterpret_cast<const td_f32x4 *>(src);
+            }
+        };
+        auto process = [&](int q, uint32_t act, uint32_t rd, td_f32x4 (&ev)[TD_WIDE_K]) {
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&fs[q][TD_F_ROW]);
+            const uint32_t r0 = rw[base], r1 = rw[base + 1], r2 = rw[base + 2], r3 = rw[base + 3];
+            const uint32_t tw = level == 0 ? (r0 | r1 | r2 | r3) : level == 1 ? (r1 | r2 | r3) : level == 2 ? ((r0 & r1) | r2 | r3) : (r2 | r3);
+            const float4 db = *reinterpret_cast<const float4 *>(&fs[q][TD_F_DB1 + n0]);
+            const float cf = cs[q];
+            float *eg = v.e + (gb + q) * TD_LD + tid * 4;
+#pragma unroll
+            for (int k = 0; k < TD_WIDE_K; ++k) {
+                if (!((act >> k) & 1u)) continue;
+                td_f32x4 x = ((rd >> k) & 1u) ? ev[k] : (td_f32x4){0.f, 0.f, 0.f, 0.f};
+                bool wr;
+                if (k < TD_WIDE_KL) {
+                    const int pos = pos0 + (TD_WIDE_CPG / 8) * k;
+                    float xj = (float)((tw >> pos) & 1u);
+                    if (level == 3) {
+                        const int cnt = (int)(((r0 >> pos) & 1u) | (((r1 >> pos) & 1u) << 1) | (((r2 >> pos) & 1u) << 2) | (((r3 >> pos) & 1u) << 3));
+                        xj = cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f;
+                    }
+                    x.x = fmaf(emul, x.x, (db.x * xj) * ginv);
+                    x.y = fmaf(emul, x.y, (db.y * xj) * ginv);
+                    x.z = fmaf(emul, x.z, (db.z * xj) * ginv);
+                    x.w = fmaf(emul, x.w, (db.w * xj) * ginv);
+                    wr = xj != 0.0f;
+                } else {
+                    const float xj = t_w1 ? td_feature_value(rw, 192 + c) : 1.0f;
+                    x.x = fmaf(emul, x.x, (fs[q][ia[0]] * (t_w1 ? xj : xfix[0])) * ginv);
+                    x.y = fmaf(emul, x.y, (fs[q][ia[1]] * (t_w1 ? xj : xfix[1])) * ginv);
+                    x.z = fmaf(emul, x.z, (fs[q][ia[2]] * (t_w1 ? xj : xfix[2])) * ginv);
+                    x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (t_w1 ? xj : xfix[3])) * ginv);
+                    wr = !t_w1 || xj != 0.0f;
+                }
+                if (full || wr || !((rd >> k) & 1u)) td_store_wt(reinterpret_cast<td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)), x);
+                acc[k].x = fmaf(cf, x.x, acc[k].x);
+                acc[k].y = fmaf(cf, x.y, acc[k].y);
+                acc[k].z = fmaf(cf, x.z, acc[k].z);
+                acc[k].w = fmaf(cf, x.w, acc[k].w);
+            }
+        };
+        uint32_t actA, rdA, actB, rdB;
+        td_f32x4 evA[TD_WIDE_K], evB[TD_WIDE_K];
+        issue(0, actA, rdA, evA);
+        for (int q0 = 0; q0 < m; q0 += 2) {
+            issue(q0 + 1, actB, rdB, evB);                    // game q0 + 1 is on its way while game q0 is computed and stored
+            process(q0, actA, rdA, evA);
+            if (q0 + 1 >= m) break;
+            issue(q0 + 2, actA, rdA, evA);
+            process(q0 + 1, actB, rdB, evB);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TD_WIDE_K; ++k)
+        if (k < TD_WIDE_KL || t_in)
+            td_store_wt(reinterpret_cast<td_f32x4 *>(v.partial + (long long)blockIdx.x * TD_LD + (k * TD_WIDE_THREADS + tid) * 4), acc[k]);
+}
+
+// block 256 = 16 float4 (64 consecutive INTERNAL positions) x 16 group lanes: a thread sums every 16th partial row of its float4
+// (a 16-byte load each: a quarter of the load instructions of the one-float-per-thread form, the same bytes), the 16 lanes meet
+// in LDS in a fixed order.  upd (optional) receives the summed update; apply adds it to theta.
 __global__ __launch_bounds__(256) void td_reduce_kernel(TdView v, int n_groups, float *upd, int apply)
 {
-    __shared__ float red[4][64];
-    const int pi = threadIdx.x & 63, gl = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + pi;                      // INTERNAL position (the partial sums' order)
-    float s = 0.0f;
-    if (q < TD_P) {
-#pragma unroll 8
-        for (int g = gl; g < n_groups; g += 4) s += v.partial[(long long)g * TD_LD + q];
-    }
-    red[gl][pi] = s;
+    __shared__ td_f32x4 red[16][16];
+    const int p4 = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int q0 = blockIdx.x * 64 + p4 * 4;                  // INTERNAL position (the partial sums' order); TD_LD is a multiple of 64
+    td_f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int g = gl; g < n_groups; g += 16) s += *reinterpret_cast<const td_f32x4 *>(v.partial + (long long)g * TD_LD + q0);
+    red[gl][p4] = s;
     __syncthreads();
-    if (gl == 0 && q < TD_P) {
-        const float u = (red[0][pi] + red[1][pi]) + (red[2][pi] + red[3][pi]);
-        const int p = td_param_of_internal(q);               // parameter order of theta / the update handed out
-        if (upd) upd[p] = u;
-        if (apply) {
-            const float th = v.theta[p] + u;
-            v.theta[p] = th;
-            if (q < TD_OFF_B1) {
-                v.w1t[q] = th;                               // w1t is [j][n]: the internal order of the W1 block
-                root3_store_weight(v.wl3, q & (N_HID - 1), q >> 7, th);
+    if (threadIdx.x < 64) {
+        const int q = blockIdx.x * 64 + threadIdx.x;
+        const int f4 = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float u = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) u += red[g][f4][e];
+        if (q < TD_P) {
+            const int p = td_param_of_internal(q);           // parameter order of theta / the update handed out
+            if (upd) upd[p] = u;
+            if (apply) {
+                const float th = v.theta[p] + u;
+                v.theta[p] = th;
+                if (q < TD_OFF_B1) {
+                    v.w1t[q] = th;                           // w1t is [j][n]: the internal order of the W1 block
+                    root3_store_weight(v.wl3, q & (N_HID - 1), q >> 7, th);
+                }
             }
         }
     }

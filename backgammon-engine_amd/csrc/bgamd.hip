@@ -1650,6 +1650,9 @@ struct bgamd_td {
     long long direct_min = 512;            // ... from which it runs as one workgroup per 32-row tile, weights from the L2 (BGAMD_TD_DIRECT_MIN)
     long long nt_min = 8192;               // ... from which the whole-row trace pass uses nontemporal loads / stores (BGAMD_TD_NT_MIN)
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
+    bool pipe = true;                      // mid-sized steps: the software-pipelined whole-row pass (BGAMD_TD_PIPE=0: td_trace_wide_kernel)
+    long long slice_ng = 0;                // BGAMD_TD_NG: games per group of the slice kernel at mid-sized steps (0: as many groups as allowed)
+    bool no_wide_even = false;             // BGAMD_TD_NO_WIDE_EVEN=1: mid-sized steps never take the whole-row kernels
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
     bool stream_mode = false;              // bgamd_td_begin_stream: slots take game after game, steps are not bounded by the log length
@@ -1727,6 +1730,9 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     v.dense = getenv("BGAMD_TD_DENSE") != nullptr ? 1 : 0;
     if (getenv("BGAMD_TD_WIDE_MIN")) td->wide_min = atoll(getenv("BGAMD_TD_WIDE_MIN"));
     if (getenv("BGAMD_TD_NT_MIN")) td->nt_min = atoll(getenv("BGAMD_TD_NT_MIN"));
+    td->pipe = !(getenv("BGAMD_TD_PIPE") && atoi(getenv("BGAMD_TD_PIPE")) == 0);
+    if (getenv("BGAMD_TD_NG")) td->slice_ng = atoll(getenv("BGAMD_TD_NG"));
+    td->no_wide_even = getenv("BGAMD_TD_NO_WIDE_EVEN") != nullptr && atoi(getenv("BGAMD_TD_NO_WIDE_EVEN")) != 0;
     td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
@@ -1876,6 +1882,10 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
 #define BG_TD_MIN_NG 4
 #endif
     if (ng < BG_TD_MIN_NG) ng = BG_TD_MIN_NG;
+    if (td->slice_ng > 0 && n_active >= 512 && n_active < td->wide_min) {       // mid-sized steps on the slice kernel: fewer, larger groups
+        ng = td->slice_ng;                                                       //   (fewer partial rows for the reduce kernel to read)
+        if ((n_active + ng - 1) / ng > TD_MAX_GROUPS) ng = (n_active + TD_MAX_GROUPS - 1) / TD_MAX_GROUPS;
+    }
     int n_groups = (int)((n_active + ng - 1) / ng);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (td->timing) {
@@ -1890,7 +1900,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     // whole-row workgroups take chunks of TD_CHUNK games: below wide_min they pay only when the chunks divide evenly over the CUs
     // (a streamed replay through 2 048 or 4 096 slots: 143 vs 147 and 110 vs 118 ms per 65 536-game round)
     const long long per_wave_of_blocks = (long long)td->n_cu * TD_CHUNK;
-    const bool wide_even = n_active >= per_wave_of_blocks && td->wide_min > per_wave_of_blocks &&
+    const bool wide_even = !td->no_wide_even && n_active >= per_wave_of_blocks && td->wide_min > per_wave_of_blocks &&
                            n_active * 20 >= ((n_active + per_wave_of_blocks - 1) / per_wave_of_blocks) * per_wave_of_blocks * 19;
     if (n_active >= td->wide_min || wide_even) {
         // large rounds: a workgroup per whole trace row and strided chunks of games (bg_learner.h)
@@ -1898,7 +1908,13 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         if (n_groups > td->n_cu) n_groups = td->n_cu;
         if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
         const bool nt = n_active >= td->nt_min;
-        if (t == 0)
+        if (td->pipe && !nt && n_active <= (long long)td->n_cu * TD_CHUNK * 4) {
+            // mid-sized steps (at most a few chunks per CU): the software-pipelined whole-row pass (bg_learner.h)
+            if (t == 0)
+                hipLaunchKernelGGL((td_trace_pipe_kernel<true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);
+            else
+                hipLaunchKernelGGL((td_trace_pipe_kernel<false>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
+        } else if (t == 0)
             hipLaunchKernelGGL((td_trace_wide_kernel<true, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);
         else if (nt)
             hipLaunchKernelGGL((td_trace_wide_kernel<false, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, full);
