@@ -640,6 +640,8 @@ struct bgamd_env {
     size_t tmp_bytes = 0;
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
+    bool root_resident = false;            // BGAMD_ROOT_RESIDENT=1: the bf16 x 3 root pass with W1 resident in registers (same bits; measured: root pass
+                                           //   0.0260 vs 0.0270 ms, leaf stage 0.0257 vs 0.0285, value net 0.0808 vs 0.0801, step 0.1501 vs 0.1504 -- no gain)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
     unsigned timing_stride = 1;            // ... on every timing_stride-th launch of the group (an event pair costs ~4 us)
@@ -755,6 +757,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
+    env->root_resident = getenv("BGAMD_ROOT_RESIDENT") != nullptr && atoi(getenv("BGAMD_ROOT_RESIDENT")) != 0;
     // round 3's K-compacted MFMA delta kernel (bg_eval_mfma.h) is correct and canonical but measured 10 % slower than the VALU
     // kernel on the same box: opt-in
     env->mfma_delta = getenv("BGAMD_MFMA_DELTA") != nullptr && atoi(getenv("BGAMD_MFMA_DELTA")) != 0;
@@ -1315,7 +1318,13 @@ struct GreedyRun {
                                        (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
                                        (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
                                        (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-                else {
+                else if (env->root_resident) {
+                    long long blocks = (n + 31) / 32;
+                    if (blocks > 2ll * ss.n_cu) blocks = 2ll * ss.n_cu;                 // two 4-wave workgroups per CU (256 VGPRs each wave)
+                    hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS),
+                                       ROOTR_LDS_BYTES, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
+                                       (const uint2 *)env->d_lut, b1, sv.root_hidden);
+                } else {
                     long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
                     if (blocks > ss.n_cu) blocks = ss.n_cu;
                     hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
@@ -1570,11 +1579,19 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
     hipLaunchKernelGGL(pack_child_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_root_index, (long long)n,
                        (long long)n_roots, (const uint4 *)sv.root_rows, sv.u_rows, sv.u_info, &env->v.counters[C_ERR]);
     HIPCHK(hipMemsetAsync(sv.best, 0, (size_t)n_roots * 8, s));
-    long long blocks = ((n_roots + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
-    if (blocks > env->n_cu) blocks = env->n_cu;
-    hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s,
-                       (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
-                       sv.root_hidden);
+    if (env->root_resident) {
+        long long blocks = (n_roots + 31) / 32;
+        if (blocks > 2ll * env->n_cu) blocks = 2ll * env->n_cu;
+        hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS), ROOTR_LDS_BYTES, s,
+                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
+                           sv.root_hidden);
+    } else {
+        long long blocks = ((n_roots + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
+        if (blocks > env->n_cu) blocks = env->n_cu;
+        hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s,
+                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
+                           sv.root_hidden);
+    }
     long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;
     dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
     KTimer t(env, s, 1);
