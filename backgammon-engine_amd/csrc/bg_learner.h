@@ -954,7 +954,8 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v
             // number of loads in flight is static and the wait before game q's arithmetic is a counted vmcnt that leaves game q + 1's
             // loads in flight (conditional loads made the compiler wait for vmcnt(0): no pipelining at all)
             const float *eg = v.e + (gb + (q < m ? q : 0)) * TD_LD + tid * 4;
-            const float *dummy = v.partial;
+            const float *dummy = v.partial + (size_t)TD_MAX_GROUPS * TD_LD;      // 16 zeroed bytes behind the partial sums: a position
+                                                                                //   that is not read needs no select, it reads 0
 #pragma unroll
             for (int k = 0; k < TD_WIDE_K; ++k) {
                 const float *src = ((rd >> k) & 1u) ? eg + k * (TD_WIDE_THREADS * 4) : dummy;
@@ -966,25 +967,31 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v
             const uint32_t r0 = rw[base], r1 = rw[base + 1], r2 = rw[base + 2], r3 = rw[base + 3];
             const uint32_t tw = level == 0 ? (r0 | r1 | r2 | r3) : level == 1 ? (r1 | r2 | r3) : level == 2 ? ((r0 & r1) | r2 | r3) : (r2 | r3);
             const float4 db = *reinterpret_cast<const float4 *>(&fs[q][TD_F_DB1 + n0]);
-            const float cf = cs[q];
+            const float4 dg = make_float4(db.x * ginv, db.y * ginv, db.z * ginv, db.w * ginv);   // thermometer levels: x_j is 0 or 1, and
+            const float cf = cs[q];                                                             //   (db x_j) ginv = x_j ? db ginv : 0 to the bit
             float *eg = v.e + (gb + q) * TD_LD + tid * 4;
 #pragma unroll
             for (int k = 0; k < TD_WIDE_K; ++k) {
                 if (!((act >> k) & 1u)) continue;
-                td_f32x4 x = ((rd >> k) & 1u) ? ev[k] : (td_f32x4){0.f, 0.f, 0.f, 0.f};
+                td_f32x4 x = ev[k];                                     // (zero where the position is not read: the dummy line)
                 bool wr;
                 if (k < TD_WIDE_KL) {
                     const int pos = pos0 + (TD_WIDE_CPG / 8) * k;
-                    float xj = (float)((tw >> pos) & 1u);
                     if (level == 3) {
                         const int cnt = (int)(((r0 >> pos) & 1u) | (((r1 >> pos) & 1u) << 1) | (((r2 >> pos) & 1u) << 2) | (((r3 >> pos) & 1u) << 3));
-                        xj = cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f;
+                        const float xj = cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f;
+                        x.x = fmaf(emul, x.x, (db.x * xj) * ginv);
+                        x.y = fmaf(emul, x.y, (db.y * xj) * ginv);
+                        x.z = fmaf(emul, x.z, (db.z * xj) * ginv);
+                        x.w = fmaf(emul, x.w, (db.w * xj) * ginv);
+                        wr = xj != 0.0f;
+                    } else {
+                        wr = ((tw >> pos) & 1u) != 0u;
+                        x.x = fmaf(emul, x.x, wr ? dg.x : 0.0f);
+                        x.y = fmaf(emul, x.y, wr ? dg.y : 0.0f);
+                        x.z = fmaf(emul, x.z, wr ? dg.z : 0.0f);
+                        x.w = fmaf(emul, x.w, wr ? dg.w : 0.0f);
                     }
-                    x.x = fmaf(emul, x.x, (db.x * xj) * ginv);
-                    x.y = fmaf(emul, x.y, (db.y * xj) * ginv);
-                    x.z = fmaf(emul, x.z, (db.z * xj) * ginv);
-                    x.w = fmaf(emul, x.w, (db.w * xj) * ginv);
-                    wr = xj != 0.0f;
                 } else {
                     const float xj = t_w1 ? td_feature_value(rw, 192 + c) : 1.0f;
                     x.x = fmaf(emul, x.x, (fs[q][ia[0]] * (t_w1 ? xj : xfix[0])) * ginv);
@@ -1015,6 +1022,292 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v
     for (int k = 0; k < TD_WIDE_K; ++k)
         if (k < TD_WIDE_KL || t_in)
             td_store_wt(reinterpret_cast<td_f32x4 *>(v.partial + (long long)blockIdx.x * TD_LD + (k * TD_WIDE_THREADS + tid) * 4), acc[k]);
+}
+
+// A mid-sized training step in TWO launches instead of three: the forward pass of a chunk's TD_CHUNK slots (td_forward_mfma_kernel's
+// product and epilogue, on a half-filled 32-row tile) runs in the trace workgroup that owns those slots, leaves the factor rows,
+// coefficients and masks in LDS -- no `fac` / `coef` round trip through memory, no staging -- and the software-pipelined whole-row
+// trace pass (td_trace_pipe_kernel) follows behind one block barrier.  The forward kernel of such a step is a latency chain of 10.8 us
+// on 128 workgroups plus a kernel boundary; here every CU computes the 16 rows it needs itself while nothing else could run.
+// Same arithmetic in the same order as the two kernels it replaces: same bits.
+template <bool FIRST>
+__global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v, long long t, long long n_active, double alpha, float emul, float ginv,
+                                                                        float cmul, int full)
+{
+    static_assert(TD_WIDE_THREADS == 512 && TD_CHUNK == 8, "written for 512-thread workgroups and chunks of 8 slots");
+    constexpr int G = TD_CHUNK;
+    __shared__ __attribute__((aligned(16))) float fs[G][TD_FLD];
+    __shared__ float cs[G];
+    __shared__ uint32_t ms[G][TD_MASK_WORDS], ns[G][TD_MASK_WORDS];
+    __shared__ uint2 sLut[16];
+    __shared__ float sd[2 * G][N_HID + 1];
+    __shared__ uint32_t srow[G][8], smask[G][TD_MASK_WORDS];
+    __shared__ float outs[2 * G], gs[G];
+    __shared__ unsigned int s_colsg[G], s_wrg[G];
+    __shared__ int adv[G], lives[G];
+    const int tid = threadIdx.x;
+    // ---- trace-pass thread constants (td_trace_wide_kernel's mapping)
+    const int c = tid >> 5;
+    const int n0 = (tid & 31) * 4;
+    const int base = 4 * ((c >> 2) & 1), level = c & 3;
+    const int pos0 = (c >> 3) + 1;
+    const bool t_w1 = tid < 192, t_in = tid < 272;
+    int ia[4];
+    float xfix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = (TD_WIDE_KL * TD_WIDE_THREADS + tid) * 4 + u;
+        xfix[u] = 1.0f;
+        if (p < TD_OFF_B1) ia[u] = TD_F_DB1 + (p & (N_HID - 1));
+        else if (p < TD_OFF_W2) ia[u] = TD_F_DB1 + (p - TD_OFF_B1);
+        else if (p < TD_OFF_B2) ia[u] = TD_F_GH + (p - TD_OFF_W2);
+        else if (p == TD_OFF_B2) ia[u] = TD_F_G;
+        else { ia[u] = TD_F_G; xfix[u] = 0.0f; }
+    }
+    // ---- forward-pass thread constants (td_forward_mfma_kernel's mapping, waves 0-3 only)
+    const bool fw = tid < 256;
+    const int lane = tid & 63, fc = (tid >> 6) & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = 32 * fc + r;
+    if (tid < 16) sLut[tid] = v.lut[tid];
+
+    {   // ONE chunk per workgroup (the launch has a workgroup per chunk: n_active <= CUs x TD_CHUNK; larger steps take two launches) --
+        // the forward pass's 156 weight registers and the trace pass's 156 of loads in flight + 52 of partial sums then never coexist
+        const long long i0 = (long long)blockIdx.x * G;
+        const long long left = n_active - i0;
+        const int m = left < G ? (int)left : G;
+        __syncthreads();                                             // sLut
+        // =============================== forward pass of slots i0 .. i0 + 7 ===============================
+        if (tid < G) { s_colsg[tid] = 0; s_wrg[tid] = 0; adv[tid] = 0; lives[tid] = 0; }
+        if (tid < G * TD_MASK_WORDS) (&smask[0][0])[tid] = 0;
+        float hv[16];
+        float w2n = 0.0f;
+        if (fw) {
+            const TrajRowsFetch fetch{v.rows, v.gmeta, t, v.n_lanes, v.T};
+            uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool row_ok = false;
+            if (r < 2 * G && (i0 * 2 + r) < 2 * n_active) {
+                uint4 u0, u1;
+                if (fetch.get(i0 * 2 + r, u0, u1)) {
+                    row_ok = true;
+                    p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+                }
+            }
+            if (fc == 0 && h == 0 && (r & 1) == 0 && r < 2 * G) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) srow[r >> 1][k] = p[k];
+            }
+            const float bb = v.theta[TD_OFF_B1 + n];
+            w2n = v.theta[TD_OFF_W2 + n];
+            const uint4 *wp = reinterpret_cast<const uint4 *>(v.wl3) + (size_t)fc * 64 + lane;
+            const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+            floatx16 a16 = {0};
+#pragma unroll
+            for (int s = 0; s < K16_STEPS; ++s) {
+                union { uint4 u; bf16x8 v; } a;
+                if (s < 12) {
+                    const int pos = 2 * s + h + 1;
+                    const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+                    a.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                } else {
+                    const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+                    const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
+                    const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+                    const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+                    a.u = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+                }
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    union { uint4 u; bf16x8 v; } wv;
+                    wv.u = wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
+                    a16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wv.v, a16, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                hv[j] = td_sigmoid(a16[j] + bb);
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (row < 2 * G) sd[row][n] = w2n * hv[j];
+            }
+        }
+        __syncthreads();                                             // srow, sd
+        if (tid < G * 16) {                                          // ever-active feature masks: thread = (game, two board points | tail)
+            const int g = tid >> 4, q = tid & 15;
+            if (i0 + g < n_active) {
+#pragma unroll
+                for (int pt = q; pt < 25; pt += 16) {
+                    const uint32_t bits = td_nonzero_bits(srow[g], pt);
+                    if (bits) atomicOr(&smask[g][pt >> 2], bits << (8 * (pt & 3)));
+                }
+            }
+        }
+        if (tid < 2 * G * 8) {                                       // output unit: thread = (row, eighth of the hidden layer)
+            const int row = tid >> 3, e8 = tid & 7;
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < N_HID / 8; ++k) sum += sd[row][e8 * (N_HID / 8) + k];
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            if (e8 == 0) outs[row] = td_sigmoid(sum + v.theta[TD_OFF_B2]);
+        }
+        __syncthreads();
+        if (tid < G) {                                               // delta, g, coef per game
+            const long long i = i0 + tid;
+            float g = 0.0f, cf = 0.0f;
+            if (i < n_active) {
+                const int4 gm = v.gmeta[i];
+                const long long tl = t - gm.w;
+                if (tl < gm.y) {
+                    const float val = outs[2 * tid], vnext = outs[2 * tid + 1];
+                    const float z = gm.z ? 1.0f : 0.0f;
+                    const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
+                    g = val * (1.0f - val);
+                    cf = (float)(alpha * (double)delta);
+                    v.sq[i] += (double)delta * (double)delta;
+                    v.nupd[i] += 1u;
+                    lives[tid] = 1 + (tl == 0 ? 1 : 0);
+                    if (tl + 1 >= gm.y) adv[tid] = 1;
+                }
+                v.coef[i] = cf;
+            }
+            gs[tid] = g;
+            cs[tid] = cf * cmul;
+        }
+        __syncthreads();
+        // factor rows of the chunk's games, straight into the trace pass's LDS image (a slot without a running game: zeros)
+        if (fw) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (row < 2 * G) {
+                    const int g = row >> 1;
+                    const float gg = lives[g] ? gs[g] : 0.0f, hh = hv[j];
+                    fs[g][TD_F_DB1 + n] = (gg * w2n) * (1.0f - hh) * hh;
+                    fs[g][TD_F_GH + n] = gg * hh;
+                }
+            }
+        }
+        if (tid < G * 9) {
+            const int g = tid / 9, k = tid % 9;
+            if (k < 8) fs[g][TD_F_ROW + k] = __uint_as_float(srow[g][k]);
+            else fs[g][TD_F_G] = lives[g] ? gs[g] : 0.0f;
+        }
+        if (tid < G * TD_MASK_WORDS) {
+            const int g = tid / TD_MASK_WORDS, wd = tid % TD_MASK_WORDS;
+            const long long i = i0 + g;
+            uint32_t am = 0u, an = 0u;
+            if (i < n_active) {
+                const bool run = lives[g] != 0, first = lives[g] == 2;
+                uint32_t now = smask[g][wd];
+                const uint32_t valid = wd < 6 ? 0xFFFFFFFFu : (wd == 6 ? 0x3Fu : 0u);
+                const uint32_t nz = now & valid;
+                now = v.dense ? valid : nz;
+                if (!run) now = 0u;
+                const uint32_t old = (first || !run || wd == TD_FLAG_WORD) ? 0u : v.amask[i * TD_MASK_WORDS + wd];
+                am = wd == TD_FLAG_WORD ? (run ? 1u : 0u) : (old | now);
+                an = wd == TD_FLAG_WORD ? (first ? 1u : 0u) : (now & ~old);
+                v.amask[i * TD_MASK_WORDS + wd] = am;
+                v.anew[i * TD_MASK_WORDS + wd] = an;
+                atomicAdd(&s_colsg[g], (unsigned int)__popc(old | now));
+                atomicAdd(&s_wrg[g], (unsigned int)__popc(v.full_step ? (old | now) : (run ? (nz | (now & ~old)) : 0u)));
+            }
+            ms[g][wd] = am;
+            ns[g][wd] = an;
+        }
+        __syncthreads();
+        if (tid < G && i0 + tid < n_active) {
+            v.act_cols[i0 + tid] += s_colsg[tid];
+            v.wr_cols[i0 + tid] += s_wrg[tid];
+            if (adv[tid]) td_advance_slot(v, i0 + tid, (int)(t + 1));
+        }
+        // =============================== trace pass of the same slots (td_trace_pipe_kernel) ===============================
+        const long long gb = i0;
+        td_f32x4 acc[TD_WIDE_K];
+#pragma unroll
+        for (int k = 0; k < TD_WIDE_K; ++k) acc[k] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+        auto issue = [&](int q, uint32_t &act, uint32_t &rd, td_f32x4 (&ev)[TD_WIDE_K]) {
+            act = 0; rd = 0;
+            if (q < m) {
+#pragma unroll
+                for (int k = 0; k < TD_WIDE_K; ++k) {
+                    const int sh = ((TD_WIDE_CPG * k) & 31) + c;
+                    bool a, fresh;
+                    if (k < TD_WIDE_KL || t_w1) {
+                        a = (ms[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u;
+                        fresh = FIRST || ((ns[q][(TD_WIDE_CPG * k) >> 5] >> sh) & 1u);
+                    } else { a = t_in && (ms[q][TD_FLAG_WORD] & 1u); fresh = FIRST || (ns[q][TD_FLAG_WORD] & 1u); }
+                    act |= (a ? 1u : 0u) << k;
+                    rd |= ((a && !fresh) ? 1u : 0u) << k;
+                }
+            }
+            const float *eg = v.e + (gb + (q < m ? q : 0)) * TD_LD + tid * 4;
+            const float *dummy = v.partial + (size_t)TD_MAX_GROUPS * TD_LD;      // 16 zeroed bytes behind the partial sums: a position
+                                                                                //   that is not read needs no select, it reads 0
+#pragma unroll
+            for (int k = 0; k < TD_WIDE_K; ++k) {
+                const float *src = ((rd >> k) & 1u) ? eg + k * (TD_WIDE_THREADS * 4) : dummy;
+                ev[k] = *reinterpret_cast<const td_f32x4 *>(src);
+            }
+        };
+        auto process = [&](int q, uint32_t act, uint32_t rd, td_f32x4 (&ev)[TD_WIDE_K]) {
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&fs[q][TD_F_ROW]);
+            const uint32_t r0 = rw[base], r1 = rw[base + 1], r2 = rw[base + 2], r3 = rw[base + 3];
+            const uint32_t tw = level == 0 ? (r0 | r1 | r2 | r3) : level == 1 ? (r1 | r2 | r3) : level == 2 ? ((r0 & r1) | r2 | r3) : (r2 | r3);
+            const float4 db = *reinterpret_cast<const float4 *>(&fs[q][TD_F_DB1 + n0]);
+            const float4 dg = make_float4(db.x * ginv, db.y * ginv, db.z * ginv, db.w * ginv);   // thermometer levels: x_j is 0 or 1, and
+            const float cf = cs[q];                                                             //   (db x_j) ginv = x_j ? db ginv : 0 to the bit
+            float *eg = v.e + (gb + q) * TD_LD + tid * 4;
+#pragma unroll
+            for (int k = 0; k < TD_WIDE_K; ++k) {
+                if (!((act >> k) & 1u)) continue;
+                td_f32x4 x = ev[k];                                     // (zero where the position is not read: the dummy line)
+                bool wr;
+                if (k < TD_WIDE_KL) {
+                    const int pos = pos0 + (TD_WIDE_CPG / 8) * k;
+                    if (level == 3) {
+                        const int cnt = (int)(((r0 >> pos) & 1u) | (((r1 >> pos) & 1u) << 1) | (((r2 >> pos) & 1u) << 2) | (((r3 >> pos) & 1u) << 3));
+                        const float xj = cnt > 3 ? 0.5f * (float)(cnt - 3) : 0.0f;
+                        x.x = fmaf(emul, x.x, (db.x * xj) * ginv);
+                        x.y = fmaf(emul, x.y, (db.y * xj) * ginv);
+                        x.z = fmaf(emul, x.z, (db.z * xj) * ginv);
+                        x.w = fmaf(emul, x.w, (db.w * xj) * ginv);
+                        wr = xj != 0.0f;
+                    } else {
+                        wr = ((tw >> pos) & 1u) != 0u;
+                        x.x = fmaf(emul, x.x, wr ? dg.x : 0.0f);
+                        x.y = fmaf(emul, x.y, wr ? dg.y : 0.0f);
+                        x.z = fmaf(emul, x.z, wr ? dg.z : 0.0f);
+                        x.w = fmaf(emul, x.w, wr ? dg.w : 0.0f);
+                    }
+                } else {
+                    const float xj = t_w1 ? td_feature_value(rw, 192 + c) : 1.0f;
+                    x.x = fmaf(emul, x.x, (fs[q][ia[0]] * (t_w1 ? xj : xfix[0])) * ginv);
+                    x.y = fmaf(emul, x.y, (fs[q][ia[1]] * (t_w1 ? xj : xfix[1])) * ginv);
+                    x.z = fmaf(emul, x.z, (fs[q][ia[2]] * (t_w1 ? xj : xfix[2])) * ginv);
+                    x.w = fmaf(emul, x.w, (fs[q][ia[3]] * (t_w1 ? xj : xfix[3])) * ginv);
+                    wr = !t_w1 || xj != 0.0f;
+                }
+                if (full || wr || !((rd >> k) & 1u)) td_store_wt(reinterpret_cast<td_f32x4 *>(eg + k * (TD_WIDE_THREADS * 4)), x);
+                acc[k].x = fmaf(cf, x.x, acc[k].x);
+                acc[k].y = fmaf(cf, x.y, acc[k].y);
+                acc[k].z = fmaf(cf, x.z, acc[k].z);
+                acc[k].w = fmaf(cf, x.w, acc[k].w);
+            }
+        };
+        uint32_t actA, rdA, actB, rdB;
+        td_f32x4 evA[TD_WIDE_K], evB[TD_WIDE_K];
+        issue(0, actA, rdA, evA);
+        for (int q0 = 0; q0 < m; q0 += 2) {
+            issue(q0 + 1, actB, rdB, evB);
+            process(q0, actA, rdA, evA);
+            if (q0 + 1 >= m) break;
+            issue(q0 + 2, actA, rdA, evA);
+            process(q0 + 1, actB, rdB, evB);
+        }
+#pragma unroll
+        for (int k = 0; k < TD_WIDE_K; ++k)
+            if (k < TD_WIDE_KL || t_in)
+                td_store_wt(reinterpret_cast<td_f32x4 *>(v.partial + (long long)blockIdx.x * TD_LD + (k * TD_WIDE_THREADS + tid) * 4), acc[k]);
+    }
 }
 
 // block 256 = 16 float4 (64 consecutive INTERNAL positions) x 16 group lanes: a thread sums every 16th partial row of its float4

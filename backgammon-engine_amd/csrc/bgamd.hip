@@ -1668,6 +1668,8 @@ struct bgamd_td {
     long long nt_min = 8192;               // ... from which the whole-row trace pass uses nontemporal loads / stores (BGAMD_TD_NT_MIN)
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool pipe = true;                      // mid-sized steps: the software-pipelined whole-row pass (BGAMD_TD_PIPE=0: td_trace_wide_kernel)
+    bool fuse_step = true;                 // ... with the forward pass of the same slots in the same launch (BGAMD_TD_FUSE_STEP=0: two launches)
+    long long fuse_min = 1024;             // ... from this many running slots up to one chunk per CU (BGAMD_TD_FUSE_MIN)
     long long slice_ng = 0;                // BGAMD_TD_NG: games per group of the slice kernel at mid-sized steps (0: as many groups as allowed)
     bool no_wide_even = false;             // BGAMD_TD_NO_WIDE_EVEN=1: mid-sized steps never take the whole-row kernels
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
@@ -1722,7 +1724,8 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     TDALLOC(v.coef, (size_t)max_games * 4);
     TDALLOC(v.sq, (size_t)max_games * 8);
     TDALLOC(v.gmeta, (size_t)max_games * 16);
-    TDALLOC(v.partial, (size_t)TD_MAX_GROUPS * TD_LD * 4);
+    TDALLOC(v.partial, ((size_t)TD_MAX_GROUPS * TD_LD + 64) * 4);          // + a zeroed line: the dummy source of the pipelined trace pass
+    HIPCHK(hipMemset(v.partial + (size_t)TD_MAX_GROUPS * TD_LD, 0, 64 * 4));
     TDALLOC(v.amask, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.anew, (size_t)max_games * TD_MASK_WORDS * 4);
     TDALLOC(v.act_cols, (size_t)max_games * 4);
@@ -1749,6 +1752,8 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     if (getenv("BGAMD_TD_NT_MIN")) td->nt_min = atoll(getenv("BGAMD_TD_NT_MIN"));
     td->pipe = !(getenv("BGAMD_TD_PIPE") && atoi(getenv("BGAMD_TD_PIPE")) == 0);
     if (getenv("BGAMD_TD_NG")) td->slice_ng = atoll(getenv("BGAMD_TD_NG"));
+    td->fuse_step = !(getenv("BGAMD_TD_FUSE_STEP") && atoi(getenv("BGAMD_TD_FUSE_STEP")) == 0);
+    if (getenv("BGAMD_TD_FUSE_MIN")) td->fuse_min = atoll(getenv("BGAMD_TD_FUSE_MIN"));
     td->no_wide_even = getenv("BGAMD_TD_NO_WIDE_EVEN") != nullptr && atoi(getenv("BGAMD_TD_NO_WIDE_EVEN")) != 0;
     td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
@@ -1869,7 +1874,12 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     }
     td->v.full_step = full;
     const TdView &v = td->v;
-    if (n_active >= td->mfma_min) {
+    // mid-sized steps whose trace pass takes the pipelined whole-row kernel: forward pass and trace pass in ONE launch (bg_learner.h)
+    const long long chunk_round = (long long)td->n_cu * TD_CHUNK;
+    const bool fused_step = td->fuse_step && td->pipe && !td->no_wide_even && n_active >= td->fuse_min && n_active < td->mfma_min &&
+                            n_active < td->nt_min && n_active <= chunk_round && n_active <= (long long)TD_MAX_GROUPS * TD_CHUNK;
+    if (fused_step) {
+    } else if (n_active >= td->mfma_min) {
         // the [2 G x 198] · [198 x 128] product of the step on the matrix pipe (exact bf16 x 3 split of fc1.weight, fp32
         // accumulation: the env's root pass), then the epilogue per game
         const long long n_rows = 2 * n_active;
@@ -1919,13 +1929,18 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     const long long per_wave_of_blocks = (long long)td->n_cu * TD_CHUNK;
     const bool wide_even = !td->no_wide_even && n_active >= per_wave_of_blocks && td->wide_min > per_wave_of_blocks &&
                            n_active * 20 >= ((n_active + per_wave_of_blocks - 1) / per_wave_of_blocks) * per_wave_of_blocks * 19;
-    if (n_active >= td->wide_min || wide_even) {
+    if (n_active >= td->wide_min || wide_even || fused_step) {
         // large rounds: a workgroup per whole trace row and strided chunks of games (bg_learner.h)
         n_groups = (int)((n_active + TD_CHUNK - 1) / TD_CHUNK);
         if (n_groups > td->n_cu) n_groups = td->n_cu;
         if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
         const bool nt = n_active >= td->nt_min;
-        if (td->pipe && !nt && n_active <= (long long)td->n_cu * TD_CHUNK * 4) {
+        if (fused_step) {
+            if (t == 0)
+                hipLaunchKernelGGL((td_step_fused_kernel<true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha, emul, ginv, cmul, 1);
+            else
+                hipLaunchKernelGGL((td_step_fused_kernel<false>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha, emul, ginv, cmul, full);
+        } else if (td->pipe && !nt && n_active <= (long long)td->n_cu * TD_CHUNK * 4) {
             // mid-sized steps (at most a few chunks per CU): the software-pipelined whole-row pass (bg_learner.h)
             if (t == 0)
                 hipLaunchKernelGGL((td_trace_pipe_kernel<true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)n_active, emul, ginv, cmul, 1);

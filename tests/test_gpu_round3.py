@@ -220,3 +220,50 @@ def test_game_inside_a_side_stream(bg, weights):
             assert seq == want_seq and g.getGameBoard() == want_board
             del g
     s.synchronize()
+
+
+# ---- the learner's mid-sized training step (round 3: forward + pipelined trace pass in one launch) --------------------------------
+
+def test_fused_training_step_equals_the_two_launch_step(bg, weights, monkeypatch):
+    """A streamed replay through 2 048 and 1 024 slots -- the step sizes the quality study allows -- with the round-3 step
+    (td_step_fused_kernel: the forward pass of a chunk's 8 slots inside the workgroup that then runs their software-pipelined
+    trace pass; td_reduce_kernel with 16-byte loads) against the same replay with the forward pass and the trace pass as two
+    launches (BGAMD_TD_FUSE_STEP=0) and with round 2's unpipelined trace kernel on top (BGAMD_TD_PIPE=0): the same arithmetic in the
+    same order, bit for bit; and against the float64 closed form of the same schedule."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n = 12288
+    env = bg.VecGame(n, seed=99)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    assert int((lengths > 0).sum()) > 0.99 * n
+    for slots in (2048, 1024):
+        scale = 48.0 / slots
+        out = {}
+        for tag, envs in (("fused", {}), ("two_launches", {"BGAMD_TD_FUSE_STEP": "0"}), ("round2", {"BGAMD_TD_FUSE_STEP": "0", "BGAMD_TD_PIPE": "0"})):
+            for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in envs.items():
+                monkeypatch.setenv(k, v)
+            L = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)
+            sq2, cnt2 = L.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)     # a second round on used buffers
+            out[tag] = (_np(L.theta).copy(), sq, cnt, sq2, cnt2)
+        for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE"):
+            monkeypatch.delenv(k, raising=False)
+        assert out["fused"][2] == out["two_launches"][2] == out["round2"][2] == int(_np(lengths).sum())
+        if slots == 2048:          # (at 1 024 slots the two-launch route takes the slice kernel: other partial sums, other rounding)
+            assert np.array_equal(out["fused"][0], out["two_launches"][0]) and out["fused"][1] == out["two_launches"][1] and out["fused"][3] == out["two_launches"][3]
+            assert np.array_equal(out["fused"][0], out["round2"][0])
+        else:
+            assert np.abs(out["fused"][0] - out["round2"][0]).max() < 1e-5
+        # the float64 closed form of the same streamed schedule (one round)
+        Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+        Ld.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)
+        Lh = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.8, dtype=torch.float64)
+        X = env.encode_rows(rows)
+        Lh.replay_stream(X, lengths, p1_won, slots=slots, batch_scale=scale)
+        th64 = _np(Lh.theta)
+        moved = np.abs(th64 - weights).max()
+        gap = np.abs(_np(Ld.theta) - th64).max()
+        print("streamed replay through %d slots, fused step: max |theta - float64 closed form| = %.3g (weights moved %.3g)" % (slots, gap, moved))
+        assert moved > 1e-3 and gap < 2e-4 * max(1.0, moved)
