@@ -366,21 +366,25 @@ def main():
             stage_ms = per["eval"] + per.get("root", 0.0)
             lds_tbps = ks_l * 512 / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
             occ = {}
-            try:                                          # VALU issue occupancy from the committed SQ counters (tools/valu_occupancy.py)
-                occ = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_occupancy.json")))
-            except Exception:
-                pass
+            for occ_file in ("r03_valu_occupancy.json", "r02_valu_occupancy.json"):
+                try:                                      # VALU issue occupancy from the COMMITTED SQ counters (tools/valu_occupancy.py): a number
+                    occ = json.load(open(os.path.join(ROOT, "profiles", occ_file)))     # of another run of this kernel, not of this one
+                    occ["source"] = "profiles/%s: %s" % (occ_file, occ.get("source", ""))
+                    break
+                except Exception:
+                    continue
+            mdelta = os.environ.get("BGAMD_MFMA_DELTA") == "1"        # round 3's opt-in kernel for the same stage
             ev = {"bound": "valu", "achieved": round(exec_tf, 3), "peak": PEAK_VALU_F32, "unit": "TFLOP/s",
                   "frac": round(exec_tf / PEAK_VALU_F32, 4), "traffic": None, "avg_ms": round(per["eval"], 4),
                   "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
-                  "kernel": "eval_rows_delta_kernel", "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
+                  "kernel": "eval_rows_mdelta_kernel" if mdelta else "eval_rows_delta_kernel", "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
                   "flop_per_launch": int(ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE),
                   "dense_equiv_tflops": round(eval_tf, 2), "dense_equiv_vs_f32_mfma_peak": round(eval_tf / peak, 3),
                   # second resource: one 512-byte W1 column per (row, changed feature) out of LDS, ds_read_b128
                   "lds_gather_GB_per_launch": round(ks_l * 512 / 1e9, 3), "lds_gather_TBps": round(lds_tbps, 2),
                   "lds_peak_TBps": PEAK_LDS_TBPS, "lds_frac": round(lds_tbps / PEAK_LDS_TBPS, 4),
-                  "valu_issue_occupancy": occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
-                  "valu_issue_occupancy_source": occ.get("source"),
+                  "valu_issue_occupancy": None if mdelta else occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
+                  "valu_issue_occupancy_source": None if mdelta else occ.get("source"),
                   "root_pass_kernel": "root_hidden_bf16x3_kernel",
                   "root_pass_avg_ms": round(per.get("root", 0.0), 4), "root_pass_tflops": round(root_tf, 2),
                   "root_pass_frac_of_f32_mfma_peak": round(root_tf / peak, 4),
@@ -409,13 +413,13 @@ def main():
         }
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs; bench.py cannot
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
-        for pmc_file in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pmc_file in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
                 for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_kernel<3>")):
                     if key in pmc:
                         roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
-                        roofs[name]["traffic_source"] = f"profiles/{pmc_file} (bytes per launch)"
+                        roofs[name]["traffic_source"] = f"profiles/{pmc_file} (bytes per launch; a committed PMC pass of this kernel, not measured in this run)"
                 break
             except Exception:
                 continue

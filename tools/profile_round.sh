@@ -16,3 +16,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 20 --burnin 100 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 python3 -c "import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['avg_ms'])"
+# gpurun merges at most 64 MiB back: the per-dispatch traces are not needed by tools/collect_profiles.py
+find "$OUT" -type f \( -name "*kernel_trace.csv" -o -name "*agent_info.csv" \) -delete
+du -sh "$OUT"

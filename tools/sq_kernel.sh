@@ -25,3 +25,4 @@ for sub in ("a", "b"):
         v = v[-200:]
         print("   %-32s %.4g" % (c, sum(v) / len(v)))
 PY
+find "$OUT" -type f \( -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*counter_collection.csv" \) -delete      # parsed above; keep the merge small
