@@ -99,6 +99,12 @@ struct StagedView {
     unsigned long long *best;             // [n] (ordered value bits << 32) | ~key ; 0 = no candidate
     unsigned long long *tops;             // [T_COUNT]
 };
-enum { T_D1 = 0, T_D2, T_F, T_U, T_COUNT };
+// The list counters live on their own 128-byte lines: the roots' two allocations (T_F and T_D1, from every workgroup at the same moment)
+// and the stages' queue up at the memory side per LINE, not per address (BG_CTR_STRIDE=1: the four counters in one 32-byte group, as
+// up to round 2; same-box A/B: doubles plies 0.0200 -> 0.0177 ms)
+#ifndef BG_CTR_STRIDE
+#define BG_CTR_STRIDE 16
+#endif
+enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_COUNT = 4 * BG_CTR_STRIDE };
 
 }  // namespace bg

@@ -31,7 +31,15 @@ using namespace bg;
 
 namespace {
 
-enum { C_ARENA_TOP = 0, C_STEPS, C_FINISHED, C_P1WINS, C_CAND_RAW, C_ROWS_EVAL, C_ERR, C_FNODES, C_DNODES, C_KSTEPS, C_COUNT };
+// Env counters, one 128-byte line each (BG_STAT_STRIDE=1: packed, as up to round 2).  Atomics queue up at the memory side per LINE: the
+// boundary launch's three statistics from 256 workgroups were 768 atomics on one line -- 4 us of its 18 (same-box A/B, round 3:
+// boundary 0.0182 -> 0.0139 ms).  Further copies of the statistics per group of workgroups (8, 16) measured nothing on top.
+#ifndef BG_STAT_STRIDE
+#define BG_STAT_STRIDE 16
+#endif
+enum { C_ARENA_TOP = 0, C_STEPS = BG_STAT_STRIDE, C_FINISHED = 2 * BG_STAT_STRIDE, C_P1WINS = 3 * BG_STAT_STRIDE, C_CAND_RAW = 4 * BG_STAT_STRIDE,
+       C_ROWS_EVAL = 5 * BG_STAT_STRIDE, C_ERR = 6 * BG_STAT_STRIDE, C_FNODES = 7 * BG_STAT_STRIDE, C_DNODES = 8 * BG_STAT_STRIDE,
+       C_KSTEPS = 9 * BG_STAT_STRIDE, C_COUNT = 10 * BG_STAT_STRIDE };
 enum { ERRF_ARENA = 1, ERRF_STATE = 2, ERRF_DELTA = 4 };
 constexpr uint32_t META_FINISHED = 1u << 12;
 
