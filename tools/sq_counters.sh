@@ -16,4 +16,4 @@ python3 tools/pmc_parse.py "$OUT/sq_a" > "$OUT/sq_counters.txt"
 python3 tools/pmc_parse.py "$OUT/sq_b" >> "$OUT/sq_counters.txt"
 cat "$OUT/sq_counters.txt"
 python3 tools/valu_occupancy.py "$OUT/sq_counters.txt" --json "$OUT/valu_occupancy.json"
-find "$OUT" -type f \( -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*counter_collection.csv" \) -delete   # parsed above; keep the merge small
+find "$OUT/sq_a" "$OUT/sq_b" -type f \( -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*counter_collection.csv" \) -delete   # parsed above; keep the merge small
