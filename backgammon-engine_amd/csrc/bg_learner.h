@@ -1091,6 +1091,15 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v
         float hv[16];
         float w2n = 0.0f;
         if (fw) {
+            // the first K-steps' weight planes are requested BEFORE the slot's rows (game record -> row: two dependent loads): they do not
+            // depend on them, and behind them they would wait a third round trip
+            constexpr int W_AHEAD = 3;
+            const uint4 *wp = reinterpret_cast<const uint4 *>(v.wl3) + (size_t)fc * 64 + lane;
+            uint4 wahead[W_AHEAD][3];
+#pragma unroll
+            for (int s = 0; s < W_AHEAD; ++s)
+#pragma unroll
+                for (int part = 0; part < 3; ++part) wahead[s][part] = wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
             const TrajRowsFetch fetch{v.rows, v.gmeta, t, v.n_lanes, v.T};
             uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             bool row_ok = false;
@@ -1107,7 +1116,6 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v
             }
             const float bb = v.theta[TD_OFF_B1 + n];
             w2n = v.theta[TD_OFF_W2 + n];
-            const uint4 *wp = reinterpret_cast<const uint4 *>(v.wl3) + (size_t)fc * 64 + lane;
             const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
             floatx16 a16 = {0};
 #pragma unroll
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
                     union { uint4 u; bf16x8 v; } wv;
-                    wv.u = wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
+                    wv.u = s < W_AHEAD ? wahead[s][part] : wp[(size_t)part * ROOT3_PART_U4 + (size_t)s * 4 * 64];
                     a16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wv.v, a16, 0, 0, 0);
                 }
             }
