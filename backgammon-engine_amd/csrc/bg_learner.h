@@ -1030,12 +1030,14 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v
 // trace pass (td_trace_pipe_kernel) follows behind one block barrier.  The forward kernel of such a step is a latency chain of 10.8 us
 // on 128 workgroups plus a kernel boundary; here every CU computes the 16 rows it needs itself while nothing else could run.
 // Same arithmetic in the same order as the two kernels it replaces: same bits.
-template <bool FIRST>
+// G = slots per workgroup: the host picks the smallest of 1, 2, 4, 8, 16 that needs no more workgroups than there are CUs -- a step of
+// 1 024 slots runs on all 256 CUs with four games each instead of on 128 with eight (its trace pass halves), a step of 4 096 slots keeps
+// the two-launch form with a FULL 32-row tile in the forward pass instead of falling back to three launches.
+template <bool FIRST, int G>
 __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v, long long t, long long n_active, double alpha, float emul, float ginv,
                                                                         float cmul, int full)
 {
-    static_assert(TD_WIDE_THREADS == 512 && TD_CHUNK == 8, "written for 512-thread workgroups and chunks of 8 slots");
-    constexpr int G = TD_CHUNK;
+    static_assert(TD_WIDE_THREADS == 512 && G >= 1 && G <= 16 && (G & (G - 1)) == 0, "512-thread workgroups, 2 G rows in one 32-row tile");
     __shared__ __attribute__((aligned(16))) float fs[G][TD_FLD];
     __shared__ float cs[G];
     __shared__ uint32_t ms[G][TD_MASK_WORDS], ns[G][TD_MASK_WORDS];

@@ -1677,7 +1677,8 @@ struct bgamd_td {
     long long wide_min = 8192;             // running games from which the trace pass uses the whole-row workgroups (BGAMD_TD_WIDE_MIN)
     bool pipe = true;                      // mid-sized steps: the software-pipelined whole-row pass (BGAMD_TD_PIPE=0: td_trace_wide_kernel)
     bool fuse_step = true;                 // ... with the forward pass of the same slots in the same launch (BGAMD_TD_FUSE_STEP=0: two launches)
-    long long fuse_min = 1024;             // ... from this many running slots up to one chunk per CU (BGAMD_TD_FUSE_MIN)
+    long long fuse_min = 512;              // ... from this many running slots (measured: 512 slots 27 vs 31 us per step, 256 slots 28 vs 26) up to 16 per CU (BGAMD_TD_FUSE_MIN)
+    int fuse_g = 0;                        // ... slots per workgroup of that launch: 0 = by step size (BGAMD_TD_FUSE_G = 1, 2, 4, 8, 16)
     long long slice_ng = 0;                // BGAMD_TD_NG: games per group of the slice kernel at mid-sized steps (0: as many groups as allowed)
     bool no_wide_even = false;             // BGAMD_TD_NO_WIDE_EVEN=1: mid-sized steps never take the whole-row kernels
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
@@ -1762,6 +1763,10 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
     if (getenv("BGAMD_TD_NG")) td->slice_ng = atoll(getenv("BGAMD_TD_NG"));
     td->fuse_step = !(getenv("BGAMD_TD_FUSE_STEP") && atoi(getenv("BGAMD_TD_FUSE_STEP")) == 0);
     if (getenv("BGAMD_TD_FUSE_MIN")) td->fuse_min = atoll(getenv("BGAMD_TD_FUSE_MIN"));
+    if (getenv("BGAMD_TD_FUSE_G")) {
+        const int g = atoi(getenv("BGAMD_TD_FUSE_G"));
+        td->fuse_g = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? g : 0;
+    }
     td->no_wide_even = getenv("BGAMD_TD_NO_WIDE_EVEN") != nullptr && atoi(getenv("BGAMD_TD_NO_WIDE_EVEN")) != 0;
     td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
@@ -1883,9 +1888,12 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     td->v.full_step = full;
     const TdView &v = td->v;
     // mid-sized steps whose trace pass takes the pipelined whole-row kernel: forward pass and trace pass in ONE launch (bg_learner.h)
-    const long long chunk_round = (long long)td->n_cu * TD_CHUNK;
+    // slots per workgroup: the smallest of 1, 2, 4, 8, 16 that asks for no more workgroups than CUs (BGAMD_TD_FUSE_G pins it)
+    const long long fuse_groups_max = td->n_cu < TD_MAX_GROUPS ? td->n_cu : TD_MAX_GROUPS;
+    int fuse_g = td->fuse_g > 0 ? td->fuse_g : 1;
+    if (td->fuse_g <= 0) while (fuse_g < 16 && (n_active + fuse_g - 1) / fuse_g > fuse_groups_max) fuse_g *= 2;
     const bool fused_step = td->fuse_step && td->pipe && !td->no_wide_even && n_active >= td->fuse_min && n_active < td->mfma_min &&
-                            n_active < td->nt_min && n_active <= chunk_round && n_active <= (long long)TD_MAX_GROUPS * TD_CHUNK;
+                            n_active < td->nt_min && (n_active + fuse_g - 1) / fuse_g <= fuse_groups_max;
     if (fused_step) {
     } else if (n_active >= td->mfma_min) {
         // the [2 G x 198] · [198 x 128] product of the step on the matrix pipe (exact bf16 x 3 split of fc1.weight, fp32
@@ -1944,10 +1952,24 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
         if (n_groups > TD_MAX_GROUPS) n_groups = TD_MAX_GROUPS;
         const bool nt = n_active >= td->nt_min;
         if (fused_step) {
-            if (t == 0)
-                hipLaunchKernelGGL((td_step_fused_kernel<true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha, emul, ginv, cmul, 1);
-            else
-                hipLaunchKernelGGL((td_step_fused_kernel<false>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha, emul, ginv, cmul, full);
+            n_groups = (int)((n_active + fuse_g - 1) / fuse_g);
+#define BG_FUSED_LAUNCH(G)                                                                                                                   \
+    do {                                                                                                                                     \
+        if (t == 0)                                                                                                                          \
+            hipLaunchKernelGGL((td_step_fused_kernel<true, G>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t,                  \
+                               (long long)n_active, alpha, emul, ginv, cmul, 1);                                                             \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((td_step_fused_kernel<false, G>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t,                 \
+                               (long long)n_active, alpha, emul, ginv, cmul, full);                                                          \
+    } while (0)
+            switch (fuse_g) {
+                case 1: BG_FUSED_LAUNCH(1); break;
+                case 2: BG_FUSED_LAUNCH(2); break;
+                case 4: BG_FUSED_LAUNCH(4); break;
+                case 8: BG_FUSED_LAUNCH(8); break;
+                default: BG_FUSED_LAUNCH(16); break;
+            }
+#undef BG_FUSED_LAUNCH
         } else if (td->pipe && !nt && n_active <= (long long)td->n_cu * TD_CHUNK * 4) {
             // mid-sized steps (at most a few chunks per CU): the software-pipelined whole-row pass (bg_learner.h)
             if (t == 0)

@@ -225,7 +225,7 @@ def test_game_inside_a_side_stream(bg, weights):
 # ---- the learner's mid-sized training step (round 3: forward + pipelined trace pass in one launch) --------------------------------
 
 def test_fused_training_step_equals_the_two_launch_step(bg, weights, monkeypatch):
-    """A streamed replay through 2 048 and 1 024 slots -- the step sizes the quality study allows -- with the round-3 step
+    """A streamed replay through 256 ... 3 072 slots -- 1 024 and 2 048 are the step sizes the quality study allows -- with the round-3 step
     (td_step_fused_kernel: the forward pass of a chunk's 8 slots inside the workgroup that then runs their software-pipelined
     trace pass; td_reduce_kernel with 16-byte loads) against the same replay with the forward pass and the trace pass as two
     launches (BGAMD_TD_FUSE_STEP=0) and with round 2's unpipelined trace kernel on top (BGAMD_TD_PIPE=0): the same arithmetic in the
@@ -236,11 +236,14 @@ def test_fused_training_step_equals_the_two_launch_step(bg, weights, monkeypatch
     env.load_weights(weights)
     rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
     assert int((lengths > 0).sum()) > 0.99 * n
-    for slots in (2048, 1024):
+    # slots per workgroup of the fused launch by step size: 2 048 -> 8 (the chunk of the two-launch route: same partial sums, same bits),
+    # 1 024 -> 4, 512 -> 2, 3 072 -> 16 (a full 32-row tile), and 1 (256 slots, only with BGAMD_TD_FUSE_MIN lowered)
+    for slots in (2048, 1024, 512, 3072, 256):
         scale = 48.0 / slots
         out = {}
-        for tag, envs in (("fused", {}), ("two_launches", {"BGAMD_TD_FUSE_STEP": "0"}), ("round2", {"BGAMD_TD_FUSE_STEP": "0", "BGAMD_TD_PIPE": "0"})):
-            for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE"):
+        fused_env = {"BGAMD_TD_FUSE_MIN": "64"} if slots == 256 else {}
+        for tag, envs in (("fused", fused_env), ("two_launches", {"BGAMD_TD_FUSE_STEP": "0"}), ("round2", {"BGAMD_TD_FUSE_STEP": "0", "BGAMD_TD_PIPE": "0"})):
+            for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE", "BGAMD_TD_FUSE_MIN"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in envs.items():
                 monkeypatch.setenv(k, v)
@@ -248,10 +251,10 @@ def test_fused_training_step_equals_the_two_launch_step(bg, weights, monkeypatch
             sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)
             sq2, cnt2 = L.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)     # a second round on used buffers
             out[tag] = (_np(L.theta).copy(), sq, cnt, sq2, cnt2)
-        for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE"):
+        for k in ("BGAMD_TD_FUSE_STEP", "BGAMD_TD_PIPE", "BGAMD_TD_FUSE_MIN"):
             monkeypatch.delenv(k, raising=False)
         assert out["fused"][2] == out["two_launches"][2] == out["round2"][2] == int(_np(lengths).sum())
-        if slots == 2048:          # (at 1 024 slots the two-launch route takes the slice kernel: other partial sums, other rounding)
+        if slots == 2048:          # (at the other sizes the routes group the games differently: other partial sums, other rounding)
             assert np.array_equal(out["fused"][0], out["two_launches"][0]) and out["fused"][1] == out["two_launches"][1] and out["fused"][3] == out["two_launches"][3]
             assert np.array_equal(out["fused"][0], out["round2"][0])
         else:
