@@ -15,10 +15,15 @@
 //                        traj_hidden_bf16x3_kernel + td_epilogue_wave_kernel   larger: the env's LDS-staged root pass, a wave per slot
 //   trace pass         the HBM-bound one: e ← λ e + ∇ (model.py:52-53 semantics, train.py:150-158) and, in the same pass, the
 //                      workgroup's share of Σ_g coef_g · e_g (train.py:159-161) -> partial sums; column-sparse and lazily
-//                      scaled (below).  td_trace_kernel (slices x groups of games) below 8 192 slots, td_trace_wide_kernel
-//                      (a workgroup per whole trace row) from there and where the chunks divide evenly
+//                      scaled (below).  td_trace_kernel (slices x groups of games) for small steps, td_trace_wide_kernel
+//                      (a workgroup per whole trace row, chunks of TD_CHUNK games) from 8 192 slots and where the chunks divide
+//                      evenly, td_trace_pipe_kernel (the same, software-pipelined over the chunk's games) for mid-sized steps
 //   td_reduce_kernel   Σ over the partial sums -> the 25 601-float update; θ += update (or hand it to the caller for
 //                      the one all-reduce of the step), W1 re-transposed and re-split for the next forward
+//   td_step_fused_kernel<FIRST, G>   (round 3) forward pass AND trace pass of a mid-sized step (512 .. 4 096 slots: what a
+//                      streamed replay at the batch sizes the quality study allows runs) in ONE launch: a workgroup owns G = 1 .. 16
+//                      slots, computes their forward pass on four of its waves and runs their pipelined whole-row trace pass behind
+//                      one block barrier -- a training step is this launch + td_reduce_kernel
 //
 // Algorithmic bytes per (game, step): 2 · 25 601 · 4 = 204 808 B of trace traffic (SURVEY §8d "learner") for DENSE traces.
 //
