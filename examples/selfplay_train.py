@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--arena", type=int, default=1024, help="lanes of the evaluation arena (2 games per lane, sides alternated)")
     ap.add_argument("--max-plies", type=int, default=600)
     ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
+    ap.add_argument("--schedule-div", type=int, default=1, help="the reference's alpha / lambda schedule is a function of the episode count "
+                    "(model.py:69-73, written for runs of ~1e5 episodes); it is evaluated at games_done // this")
     ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x2", "bf16"), default="auto",
@@ -89,7 +91,7 @@ def main():
     first_dice = None
     for r in range(a.rounds):
         games_done = r * a.games * world
-        L.update_learning_params(games_done)
+        L.update_learning_params(games_done // max(1, a.schedule_div))
         if a.lam is not None:
             L.lambda_decay = a.lam
         # linear decay of the exploration rate across the run (train.py:531)
