@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_full_lanes.py: runs in spawned processes that never touch the GPU -- numpy + the oracle (test
+infrastructure) only.  For a slice of lanes: the state the HIP step produced must be one of the oracle's afterstates of the lane's
+pre-move state and dice, with a value (fp64 restatement of the reference model) within 1e-5 of the arg-max / arg-min."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+_W = None
+_O = None
+
+
+def init(wpath):
+    global _W, _O
+    from oracle import oracle as O
+    _O = O
+    _W = np.fromfile(wpath, dtype=np.float32)
+
+
+def check(args):
+    pre, pt, dice, post = args
+    O = _O
+    worst, not_first, stuck, nrows = 0.0, 0, 0, 0
+    for i in range(len(pre)):
+        s = O.State.from28(pre[i], pt[i])
+        _, _, cand = O.evaluate_turn_sequences(s, int(pt[i]), int(dice[i, 0]), int(dice[i, 1]))
+        if len(cand) == 0:
+            if not (post[i] == pre[i]).all():
+                return ("FAIL", "a stuck lane moved", pre[i].tolist())
+            stuck += 1
+            continue
+        nrows += len(cand)
+        v = O.forward_f64(_W, O.encode(cand, int(pt[i])))
+        k = [j for j in range(len(cand)) if (cand[j] == post[i]).all()]
+        if not k:
+            return ("FAIL", "the applied state is not among the oracle's afterstates", pre[i].tolist(), post[i].tolist())
+        best = v.max() if pt[i] == 0 else v.min()
+        gap = abs(float(v[k[0]]) - float(best))
+        if gap >= 1e-5:
+            return ("FAIL", "value %g vs best %g" % (v[k[0]], best), pre[i].tolist())
+        worst = max(worst, gap)
+        first = int(np.argmax(v) if pt[i] == 0 else np.argmin(v))
+        if not (cand[first] == post[i]).all():
+            not_first += 1
+    return ("OK", worst, not_first, stuck, nrows)

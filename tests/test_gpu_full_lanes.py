@@ -1,0 +1,48 @@
+"""BASELINE.json's full size, every lane: all 65 536 lanes of a greedy step against the oracle, not a sample of them."""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bg():
+    import backgammon_env
+    return backgammon_env
+
+
+def test_every_lane_of_65536_vs_oracle(bg, golden_dir, weights):
+    """What test_greedy_65536_sampled_lanes_vs_oracle checks on 255 lanes, on ALL lanes that are live, at three phases of the games
+    (plies ~12, ~38, ~64 of greedy play, auto-reset on in between): the state every lane is in after step_greedy is one of the oracle's
+    afterstates of its pre-move state and dice (the reference's evaluateTurnSequences restated in C), and the fp64 restatement of the
+    reference model puts its value within 1e-5 of the arg-max (PLAYER1) / arg-min (PLAYER2).  The oracle work runs in spawned worker
+    processes (tests/full_lane_worker.py: numpy + oracle, no GPU)."""
+    import full_lane_worker as W
+    n = 65536
+    env = bg.VecGame(n, seed=20240603)
+    env.load_weights(weights)
+    workers = min(16, os.cpu_count() or 1)
+    wpath = os.path.join(golden_dir, "tdgammonNEW100k.f32")
+    env.run_greedy(12)
+    with mp.get_context("spawn").Pool(workers, initializer=W.init, initargs=(wpath,)) as pool:
+        for step in range(3):
+            pre, pt = env.states().cpu().numpy(), env.turns().cpu().numpy()
+            live = (env.flags().cpu().numpy() & 4) == 0
+            env.step_greedy(auto_reset=False)
+            post, dice = env.states().cpu().numpy(), env.dice().cpu().numpy()
+            idx = np.nonzero(live)[0]
+            assert len(idx) > 0.9 * n
+            t0 = time.time()
+            res = pool.map(W.check, [(pre[c], pt[c], dice[c], post[c]) for c in np.array_split(idx, workers * 8) if len(c)])
+            bad = [r for r in res if r[0] != "OK"]
+            assert not bad, bad[0]
+            print("step %d: %d live lanes checked, %d oracle afterstates, %d stuck lanes; max |value of the applied state - best| = %.3g; "
+                  "%d lanes (%.4f %%) took a state other than the fp64 oracle's first best index (all within 1e-5); %.0f s on %d workers"
+                  % (step, len(idx), sum(r[4] for r in res), sum(r[3] for r in res), max(r[1] for r in res), sum(r[2] for r in res),
+                     100.0 * sum(r[2] for r in res) / len(idx), time.time() - t0, workers), flush=True)
+            env.run_greedy(25)
+    assert env.stats()["error_flags"] == 0
