@@ -47,3 +47,21 @@ def check(args):
         if not (cand[first] == post[i]).all():
             not_first += 1
     return ("OK", worst, not_first, stuck, nrows)
+
+
+def run_random(args):
+    """Config 2: the oracle's whole env for a slice of lanes (Philox dice, reference-order enumeration, k = u32 C >> 32, apply, terminal
+    check, auto-reset) against the per-step snapshots of the HIP env: every state, turn and flag, every step."""
+    seed, lanes, n, steps, snaps, flags = args
+    O = _O
+    fin = ctot = 0
+    for j, lane in enumerate(lanes):
+        ref, f, c, _ = O.lane_run(seed, int(lane), n, steps, 0)
+        if not (ref[:, :29] == snaps[:, j].astype(np.int32)).all():
+            t = int(np.nonzero((ref[:, :29] != snaps[:, j].astype(np.int32)).any(1))[0][0])
+            return ("FAIL", int(lane), t)
+        if not (ref[:, 29] == flags[:, j]).all():
+            return ("FAIL", int(lane), "flags")
+        fin += f
+        ctot += c
+    return ("OK", fin, ctot)

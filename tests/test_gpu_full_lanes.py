@@ -46,3 +46,31 @@ def test_every_lane_of_65536_vs_oracle(bg, golden_dir, weights):
                      100.0 * sum(r[2] for r in res) / len(idx), time.time() - t0, workers), flush=True)
             env.run_greedy(25)
     assert env.stats()["error_flags"] == 0
+
+
+def test_every_lane_of_65536_random_policy_vs_oracle(bg, golden_dir):
+    """Config 2 at BASELINE's size: ALL 65 536 lanes of the random-policy env, every step of 128 (auto-reset on: most lanes finish a game and start the next), against the oracle's
+    whole-env run of the same lane (test_random_trajectories_vs_oracle_4096 at 16 x the lanes): every state, turn and step flag equal,
+    and the env's counters equal the sums over the lanes."""
+    import full_lane_worker as W
+    n, steps, seed = 65536, 128, 424242
+    env = bg.VecGame(n, seed=seed)
+    snaps = np.zeros((steps, n, 29), dtype=np.int8)
+    flags = np.zeros((steps, n), dtype=np.int8)
+    for t in range(steps):
+        env.step_random()
+        snaps[t, :, :28] = env.states().cpu().numpy()
+        snaps[t, :, 28] = env.turns().cpu().numpy()
+        flags[t] = (env.flags().cpu().numpy() >> 4) & 3
+    workers = min(16, os.cpu_count() or 1)
+    wpath = os.path.join(golden_dir, "tdgammonNEW100k.f32")
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(workers, initializer=W.init, initargs=(wpath,)) as pool:
+        chunks = np.array_split(np.arange(n), workers * 8)
+        res = pool.map(W.run_random, [(seed, c, n, steps, snaps[:, c], flags[:, c].astype(np.int32)) for c in chunks])
+    bad = [r for r in res if r[0] != "OK"]
+    assert not bad, bad[0]
+    s = env.stats()
+    assert s["games_finished"] == sum(r[1] for r in res) and s["candidates_raw"] == sum(r[2] for r in res) and s["steps"] == n * steps
+    print("random policy: %d lanes x %d steps state-for-state equal to the oracle's runs (%d games finished, %d raw candidates); %.0f s on %d workers"
+          % (n, steps, s["games_finished"], s["candidates_raw"], time.time() - t0, workers))
