@@ -22,7 +22,8 @@ def init(wpath):
 
 
 def check(args):
-    pre, pt, dice, post = args
+    pre, pt, dice, post = args[:4]
+    tol = args[4] if len(args) > 4 else 1e-5
     O = _O
     worst, not_first, stuck, nrows = 0.0, 0, 0, 0
     for i in range(len(pre)):
@@ -40,7 +41,7 @@ def check(args):
             return ("FAIL", "the applied state is not among the oracle's afterstates", pre[i].tolist(), post[i].tolist())
         best = v.max() if pt[i] == 0 else v.min()
         gap = abs(float(v[k[0]]) - float(best))
-        if gap >= 1e-5:
+        if gap >= tol:
             return ("FAIL", "value %g vs best %g" % (v[k[0]], best), pre[i].tolist())
         worst = max(worst, gap)
         first = int(np.argmax(v) if pt[i] == 0 else np.argmin(v))

@@ -74,3 +74,31 @@ def test_every_lane_of_65536_random_policy_vs_oracle(bg, golden_dir):
     assert s["games_finished"] == sum(r[1] for r in res) and s["candidates_raw"] == sum(r[2] for r in res) and s["steps"] == n * steps
     print("random policy: %d lanes x %d steps state-for-state equal to the oracle's runs (%d games finished, %d raw candidates); %.0f s on %d workers"
           % (n, steps, s["games_finished"], s["candidates_raw"], time.time() - t0, workers))
+
+
+def test_every_lane_of_32768_bf16_selfplay_vs_oracle(bg, golden_dir, weights):
+    """Config 5's per-GPU share, every lane: 32 768 lanes stepping with the bf16 value net (the speed mode outside the 1e-5 bound).  Whatever
+    the precision of the values, the MOVES must be the reference's: the state every live lane is in after the step is one of the oracle's
+    afterstates of its pre-move state and dice; and the fp64 value of the state bf16 picked is within 5e-3 of the best (measured below)."""
+    import full_lane_worker as W
+    n = 32768
+    env = bg.VecGame(n, seed=5150)
+    env.load_weights(weights)
+    workers = min(16, os.cpu_count() or 1)
+    wpath = os.path.join(golden_dir, "tdgammonNEW100k.f32")
+    env.run_greedy(10, precision=bg.BF16)
+    with mp.get_context("spawn").Pool(workers, initializer=W.init, initargs=(wpath,)) as pool:
+        for step in range(2):
+            pre, pt = env.states().cpu().numpy(), env.turns().cpu().numpy()
+            live = (env.flags().cpu().numpy() & 4) == 0
+            env.step_greedy(auto_reset=False, precision=bg.BF16)
+            post, dice = env.states().cpu().numpy(), env.dice().cpu().numpy()
+            idx = np.nonzero(live)[0]
+            res = pool.map(W.check, [(pre[c], pt[c], dice[c], post[c], 5e-3) for c in np.array_split(idx, workers * 8) if len(c)])
+            bad = [r for r in res if r[0] != "OK"]
+            assert not bad, bad[0]
+            print("bf16 step %d: %d live lanes, every applied state a legal afterstate; max fp64 value gap to the best %.3g; %d lanes (%.2f %%) "
+                  "not the fp64 oracle's first best index" % (step, len(idx), max(r[1] for r in res), sum(r[2] for r in res),
+                                                              100.0 * sum(r[2] for r in res) / len(idx)), flush=True)
+            env.run_greedy(30, precision=bg.BF16)
+    assert env.stats()["error_flags"] == 0
