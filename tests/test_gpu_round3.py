@@ -9,6 +9,7 @@
 Integer work is bit-exact; value-net outputs within 1e-5 of the reference (north_star)."""
 import gc
 import os
+import time
 
 import numpy as np
 import pytest
@@ -270,3 +271,38 @@ def test_fused_training_step_equals_the_two_launch_step(bg, weights, monkeypatch
         gap = np.abs(_np(Ld.theta) - th64).max()
         print("streamed replay through %d slots, fused step: max |theta - float64 closed form| = %.3g (weights moved %.3g)" % (slots, gap, moved))
         assert moved > 1e-3 and gap < 2e-4 * max(1.0, moved)
+
+
+def test_streamed_round_65536_games_2048_slots_vs_float64(bg, weights):
+    """The training configuration the quality study recommends, at config 4's per-GPU size: ONE round of 65 536 epsilon-greedy self-play
+    games, its replay STREAMED through 2 048 slots (2 700 training steps of the two-launch step, 96 / 2 048 of every game's update) on the
+    HIP learner -- against the float64 closed form of the same schedule over the whole round (PyTorch fp64 on the GPU), twice bit-identical,
+    every (game, step) counted."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n, slots = 65536, 2048
+    env = bg.VecGame(n, seed=60606)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=320, epsilon=0.05)
+    ln = _np(lengths)
+    assert (ln > 0).mean() > 0.995 and env.stats()["error_flags"] == 0
+    scale = 96.0 / slots
+    out = []
+    for rep in range(2):
+        Ld = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+        t0 = time.time()
+        sq, cnt = Ld.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert cnt == int(ln.sum())
+        out.append(_np(Ld.theta).copy())
+        del Ld
+        torch.cuda.empty_cache()
+    assert np.array_equal(out[0], out[1])
+    Lh = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.8, dtype=torch.float64)
+    X = env.encode_rows(rows)
+    Lh.replay_stream(X, lengths, p1_won, slots=slots, batch_scale=scale)
+    th64 = _np(Lh.theta)
+    moved, gap = np.abs(th64 - weights).max(), np.abs(out[0] - th64).max()
+    print("65 536 games (%d turns) streamed through %d slots: device replay %.0f ms; max |theta - float64 closed form| = %.3g at weights moved by %.3g"
+          % (int(ln.sum()), slots, dt * 1e3, gap, moved))
+    assert moved > 1e-2 and gap < 2e-4 * max(1.0, moved)
