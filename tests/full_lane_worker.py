@@ -66,3 +66,35 @@ def run_random(args):
         fin += f
         ctot += c
     return ("OK", fin, ctot)
+
+
+def check_eps(args):
+    """epsilon-greedy self-play (model.py:205-206 with the Philox TURN stream): a lane explores iff (x3 >> 8) 2^-24 < eps and then plays
+    reference-order candidate k = (x2 C) >> 32; every other lane plays the value-optimal afterstate."""
+    seed, n, eps, lanes, pre, pt, ply, epi, post, chosen = args
+    O = _O
+    n_explore, worst = 0, 0.0
+    for i, lane in enumerate(lanes):
+        gid = int(lane) + int(epi[i]) * n
+        d1, d2, cu, eu = O.turn_randoms(seed, gid, int(ply[i]))
+        _, _, cand = O.evaluate_turn_sequences(O.State.from28(pre[i], pt[i]), int(pt[i]), d1, d2)
+        if len(cand) == 0:
+            if not (post[i] == pre[i]).all():
+                return ("FAIL", int(lane), "a stuck lane moved")
+            continue
+        if np.float32(eu >> 8) * np.float32(1.0 / 16777216.0) < np.float32(eps):
+            k = (cu * len(cand)) >> 32
+            if chosen[i] != k or not (post[i] == cand[k]).all():
+                return ("FAIL", int(lane), "exploring lane: not candidate k")
+            n_explore += 1
+            continue
+        v = O.forward_f64(_W, O.encode(cand, int(pt[i])))
+        k = [j for j in range(len(cand)) if (cand[j] == post[i]).all()]
+        if not k:
+            return ("FAIL", int(lane), "not an afterstate")
+        best = v.max() if pt[i] == 0 else v.min()
+        gap = abs(float(v[k[0]]) - float(best))
+        if gap >= 1e-5:
+            return ("FAIL", int(lane), "value gap %g" % gap)
+        worst = max(worst, gap)
+    return ("OK", n_explore, worst)

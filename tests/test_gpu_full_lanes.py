@@ -102,3 +102,30 @@ def test_every_lane_of_32768_bf16_selfplay_vs_oracle(bg, golden_dir, weights):
                                                               100.0 * sum(r[2] for r in res) / len(idx)), flush=True)
             env.run_greedy(30, precision=bg.BF16)
     assert env.stats()["error_flags"] == 0
+
+
+def test_every_lane_of_65536_epsilon_greedy_vs_oracle(bg, golden_dir, weights):
+    """Config 4's self-play policy at its per-GPU size, every lane: step_greedy(epsilon = 0.1) on 65 536 lanes -- a lane whose TURN-stream
+    draw says "explore" (model.py:205-206) plays exactly reference-order candidate k = (x2 C) >> 32 of the oracle's enumeration, every
+    other lane plays an afterstate whose fp64 value is within 1e-5 of the best."""
+    import full_lane_worker as W
+    n, seed, eps = 65536, 97531, 0.1
+    env = bg.VecGame(n, seed=seed)
+    env.load_weights(weights)
+    env.run_greedy(20, epsilon=eps)
+    pre, pt = env.states().cpu().numpy(), env.turns().cpu().numpy()
+    ply, epi = [x.cpu().numpy() for x in env.progress()]
+    live = (env.flags().cpu().numpy() & 4) == 0
+    env.step_greedy(epsilon=eps, auto_reset=False)
+    post, chosen = env.states().cpu().numpy(), env.last_choice()["chosen"].cpu().numpy()
+    idx = np.nonzero(live)[0]
+    workers = min(16, os.cpu_count() or 1)
+    wpath = os.path.join(golden_dir, "tdgammonNEW100k.f32")
+    with mp.get_context("spawn").Pool(workers, initializer=W.init, initargs=(wpath,)) as pool:
+        res = pool.map(W.check_eps, [(seed, n, eps, c, pre[c], pt[c], ply[c], epi[c], post[c], chosen[c]) for c in np.array_split(idx, workers * 8)])
+    bad = [r for r in res if r[0] != "OK"]
+    assert not bad, bad[0]
+    n_explore = sum(r[1] for r in res)
+    print("epsilon-greedy %.2f: %d live lanes, %d explored (candidate k of the reference-order list, exactly), the others within %.3g of the best"
+          % (eps, len(idx), n_explore, max(r[2] for r in res)))
+    assert 0.08 * len(idx) < n_explore < 0.12 * len(idx)
