@@ -648,8 +648,10 @@ struct bgamd_env {
     size_t tmp_bytes = 0;
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
-    bool root_resident = false;            // BGAMD_ROOT_RESIDENT=1: the bf16 x 3 root pass with W1 resident in registers (same bits; measured: root pass
-                                           //   0.0260 vs 0.0270 ms, leaf stage 0.0257 vs 0.0285, value net 0.0808 vs 0.0801, step 0.1501 vs 0.1504 -- no gain)
+    bool root_resident = true;             // the bf16 x 3 root pass with W1 resident in registers (same bits as the LDS-staged kernel, BGAMD_ROOT_RESIDENT=0).
+                                           //   The leaf stage starts less obstructed beside it: with the counters packed (rounds 2-3a) the value net paid that
+                                           //   back (step 0.1501 vs 0.1504 ms); with every counter on its own line it does not (leaf stage 0.0302 -> 0.0260,
+                                           //   doubles plies 0.0180 -> 0.0195, step 0.1458 -> 0.1445 ms, same box, three interleaved runs)
     // kernel timing
     unsigned timing = 0;                   // bit k: bracket kernel group k with HIP events
     unsigned timing_stride = 1;            // ... on every timing_stride-th launch of the group (an event pair costs ~4 us)
@@ -765,7 +767,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         return rc;
     }
     env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
-    env->root_resident = getenv("BGAMD_ROOT_RESIDENT") != nullptr && atoi(getenv("BGAMD_ROOT_RESIDENT")) != 0;
+    env->root_resident = !(getenv("BGAMD_ROOT_RESIDENT") != nullptr && atoi(getenv("BGAMD_ROOT_RESIDENT")) == 0);
     // round 3's K-compacted MFMA delta kernel (bg_eval_mfma.h) is correct and canonical but measured 10 % slower than the VALU
     // kernel on the same box: opt-in
     env->mfma_delta = getenv("BGAMD_MFMA_DELTA") != nullptr && atoi(getenv("BGAMD_MFMA_DELTA")) != 0;

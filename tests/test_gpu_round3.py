@@ -306,3 +306,22 @@ def test_streamed_round_65536_games_2048_slots_vs_float64(bg, weights):
     print("65 536 games (%d turns) streamed through %d slots: device replay %.0f ms; max |theta - float64 closed form| = %.3g at weights moved by %.3g"
           % (int(ln.sum()), slots, dt * 1e3, gap, moved))
     assert moved > 1e-2 and gap < 2e-4 * max(1.0, moved)
+
+
+def test_resident_and_lds_staged_root_pass_are_bit_identical(bg, weights, monkeypatch):
+    """The root pass of the incremental value net exists twice: with the three bf16 planes of a wave's 32 hidden units resident in
+    registers (the default since round 3) and staged through LDS in two K phases (BGAMD_ROOT_RESIDENT=0, rounds 1-2).  Same MFMA
+    sequence per accumulator: the same games to the last bit, and the same per-row values through evaluate_incremental."""
+    n = 8192
+    monkeypatch.delenv("BGAMD_ROOT_RESIDENT", raising=False)
+    a = bg.VecGame(n, seed=4711)
+    monkeypatch.setenv("BGAMD_ROOT_RESIDENT", "0")
+    b = bg.VecGame(n, seed=4711)
+    monkeypatch.delenv("BGAMD_ROOT_RESIDENT", raising=False)
+    a.load_weights(weights); b.load_weights(weights)
+    for k in (1, 7, 40):
+        a.run_greedy(k, epsilon=0.05); b.run_greedy(k, epsilon=0.05)
+        assert torch.equal(a.states(), b.states()) and torch.equal(a.turns(), b.turns()), k
+        la, lb = a.last_choice(), b.last_choice()
+        assert torch.equal(la["value"], lb["value"]) and torch.equal(la["seq"], lb["seq"])
+    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0
