@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 3's evidence in two gpurun calls (each within the 1 200 s limit; the GPU tests run as their own call):
-#   gpurun --timeout 1150 -- 'bash tools/round_check_r3.sh step r03_v34'      bench line, rocprof stats, PMC traffic, SQ counters, driver-style bench
-#   gpurun --timeout 1150 -- 'bash tools/round_check_r3.sh learner r03_v34'   learner benches, rocprof of a replay, training round, RCCL one-rank step
+#   gpurun --timeout 1150 -- 'bash tools/round_check_r3.sh step r03_v35'      bench line, rocprof stats, PMC traffic, SQ counters, driver-style bench
+#   gpurun --timeout 1150 -- 'bash tools/round_check_r3.sh learner r03_v35'   learner benches, rocprof of a replay, training round, RCCL one-rank step
 PART=${1:?step|learner}; TAG=${2:?tag}
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
