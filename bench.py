@@ -385,7 +385,7 @@ def main():
                   "lds_peak_TBps": PEAK_LDS_TBPS, "lds_frac": round(lds_tbps / PEAK_LDS_TBPS, 4),
                   "valu_issue_occupancy": None if mdelta else occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
                   "valu_issue_occupancy_source": None if mdelta else occ.get("source"),
-                  "root_pass_kernel": "root_hidden_bf16x3_kernel",
+                  "root_pass_kernel": "root_hidden_bf16x3_kernel" if os.environ.get("BGAMD_ROOT_RESIDENT") == "0" else "root_hidden_resident_kernel",
                   "root_pass_avg_ms": round(per.get("root", 0.0), 4), "root_pass_tflops": round(root_tf, 2),
                   "root_pass_frac_of_f32_mfma_peak": round(root_tf / peak, 4),
                   "value_net_stage_ms": round(stage_ms, 4),
