@@ -325,3 +325,33 @@ def test_resident_and_lds_staged_root_pass_are_bit_identical(bg, weights, monkey
         la, lb = a.last_choice(), b.last_choice()
         assert torch.equal(la["value"], lb["value"]) and torch.equal(la["seq"], lb["seq"])
     assert a.stats() == b.stats() and a.stats()["error_flags"] == 0
+
+
+def test_f16x2_with_resident_weights_equals_the_lds_staged_f16x2_kernel(bg, weights, monkeypatch):
+    """BGAMD_F16X2_RESIDENT=1 (csrc/bg_eval_dense16.h: the dense f16 hi + lo value net with a wave's weight planes resident in registers,
+    -log2 e and b1 folded into the table) against round 1's LDS-staged f16 x 2 kernel: values within 1e-6 of each other and of the fp32
+    path's, and the same games for 40 steps (a near-tie may resolve differently: > 99.9 % of the lanes identical is asserted)."""
+    n = 4096
+    monkeypatch.delenv("BGAMD_F16X2_RESIDENT", raising=False)
+    a = bg.VecGame(n, seed=1357)
+    monkeypatch.setenv("BGAMD_F16X2_RESIDENT", "1")
+    b = bg.VecGame(n, seed=1357)
+    monkeypatch.delenv("BGAMD_F16X2_RESIDENT", raising=False)
+    c = bg.VecGame(n, seed=1357)
+    for e in (a, b, c):
+        e.load_weights(weights)
+    a.run_greedy(10, precision=bg.F16X2); b.run_greedy(10, precision=bg.F16X2); c.run_greedy(10)
+    same = (a.states() == b.states()).all(1)
+    assert same.float().mean().item() > 0.999
+    # one more step from IDENTICAL positions: chosen values side by side
+    idx = torch.nonzero(same & (a.states() == c.states()).all(1)).flatten()
+    a.step_greedy(precision=bg.F16X2, auto_reset=False); b.step_greedy(precision=bg.F16X2, auto_reset=False); c.step_greedy(auto_reset=False)
+    va, vb, vc = (e.last_choice()["value"][idx] for e in (a, b, c))
+    moved = (a.last_choice()["count"][idx] > 0)
+    d_ab, d_bc = (va - vb).abs()[moved].max().item(), (vb - vc).abs()[moved].max().item()
+    print("f16x2 resident vs LDS-staged: max |dv| = %.3g; vs the fp32 incremental path: %.3g (%d lanes)" % (d_ab, d_bc, int(moved.sum())))
+    assert d_ab < 1e-6 and d_bc < 2e-6
+    for e in (a, b):
+        e.run_greedy(30, precision=bg.F16X2)
+    assert ((a.states() == b.states()).all(1)).float().mean().item() > 0.995
+    assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
