@@ -137,3 +137,58 @@ def test_stream_schedule_library_equals_host_restatement():
         assert n_steps == max(tot)
         if games >= 4 * slots:
             assert max(tot) - min(tot) <= int(np.sort(ln[ln > 0])[: max(1, games // 4)].max()) + 1      # within a short game
+
+
+def _g9(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g9_td_lambda_multi_game.npz"))
+    off = g["off"]
+    G, T = len(off) - 1, int(np.diff(off).max())
+    X = np.zeros((T, G, 198), dtype=np.float32)
+    for k in range(G):
+        st, turn = g["states"][off[k]:off[k + 1]].astype(np.int32), g["turn"][off[k]:off[k + 1]]
+        for t in range(len(st)):
+            X[t, k] = O.encode(st[t:t + 1], int(turn[t]))[0]
+    return g, X, np.diff(off).astype(np.int64), g["winner"] == 0
+
+
+def test_g9_multi_game_order_matches_reference(golden_dir, weights):
+    """Fixture G9 (tests/golden/make_golden_r4.py): the body of the reference's round loop (train.py:536-547) over 8 of G5's games --
+    `update_learning_params` between the games (alpha steps 0.1 -> 0.096 at episode 40 000), traces reset per game, every game from the
+    weights the one before left -- through the reference's own apply_td_updates.  The host closed form, one game per replay() call with the
+    schedule in between, equals it after EVERY game (the bar of fixture G6, per game); the streamed replay through one slot and the
+    one-game sub-rounds equal the fixture's runs in those two orders at fixed alpha / lambda."""
+    from backgammon_env.learner import TDLambdaLearner
+    g, X, lengths, won = _g9(golden_dir)
+    Xt = torch.from_numpy(X)
+    G = len(lengths)
+    L = TDLambdaLearner(weights)
+    base = int(g["base_episode"])
+    prev = weights
+    for k in range(G):
+        L.update_learning_params(base + k + 1)
+        assert (L.learning_rate, L.lambda_decay) == tuple(g["alpha_lambda_sched"][k])
+        ln = np.zeros(G, dtype=np.int64); ln[k] = lengths[k]
+        sq, cnt = L.replay(Xt, ln, won)
+        assert cnt == lengths[k]
+        assert np.abs(L.theta.numpy() - g["w_sched"][k]).max() < 2e-6, k
+        assert np.abs(g["w_sched"][k] - prev).max() > 1e-4                       # every game moved the weights
+        prev = g["w_sched"][k]
+    assert g["alpha_lambda_sched"][0][0] != g["alpha_lambda_sched"][-1][0]        # the schedule did step inside the fixture
+    alpha, lam = g["alpha_lambda_fixed"]
+    # the order of a streamed replay through ONE slot
+    L = TDLambdaLearner(weights, alpha=alpha, lam=lam)
+    from backgammon_env.learner import stream_schedule
+    queue, _, _, _ = stream_schedule(torch.from_numpy(lengths), 1)
+    assert queue.tolist() == g["order_stream1"].tolist()
+    L.replay_stream(Xt, lengths, won, slots=1)
+    assert np.abs(L.theta.numpy() - g["w_stream1_final"]).max() < 2e-6
+    # sub-rounds of one game: decreasing length (what DeviceTDLambdaLearner.replay_rows(sub_round=1) runs)
+    L = TDLambdaLearner(weights, alpha=alpha, lam=lam)
+    for n_done, k in enumerate(g["order_sorted"].tolist()):
+        ln = np.zeros(G, dtype=np.int64); ln[k] = lengths[k]
+        L.replay(Xt, ln, won)
+        if n_done == 3:
+            assert np.abs(L.theta.numpy() - g["w_sorted_mid"]).max() < 2e-6
+    assert np.abs(L.theta.numpy() - g["w_sorted_final"]).max() < 2e-6
+    # the two orders are different runs: an order mix-up cannot pass
+    assert np.abs(g["w_sorted_final"] - g["w_stream1_final"]).max() > 1e-3
