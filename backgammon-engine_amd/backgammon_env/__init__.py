@@ -327,6 +327,24 @@ class VecGame:
         _capi.check(self._lib.bgamd_env_set_trajectory(self._h, _ptr(self._traj), int(max_plies)), "set_trajectory")
         return self._traj
 
+    def record_ring(self, ring_steps: int | None):
+        """Ring log of continuous self-play (bgamd_env_set_trajectory_ring): greedy steps with auto_reset log the pre-move row of every
+        lane by ENV STEP -> (rows int32 [ring_steps, n, 8], end int16 [ring_steps, n]); end != 0 where the turn logged in that slot was
+        the last of its game: (end & 0x7FFF) logged turns, end < 0: PLAYER2 won.  None drops it."""
+        if ring_steps is None:
+            self._ring = None
+            _capi.check(self._lib.bgamd_env_set_trajectory_ring(self._h, None, 0, None), "set_trajectory_ring")
+            return None
+        rows = torch.zeros((int(ring_steps), self.n, 8), dtype=torch.int32, device=self.device)
+        end = torch.zeros((int(ring_steps), self.n), dtype=torch.int16, device=self.device)
+        self._ring = (rows, end)
+        _capi.check(self._lib.bgamd_env_set_trajectory_ring(self._h, _ptr(rows), int(ring_steps), _ptr(end)), "set_trajectory_ring")
+        return rows, end
+
+    def trajectory_step(self) -> int:
+        """env steps logged into the ring so far (a host counter: no synchronisation)"""
+        return int(self._lib.bgamd_env_trajectory_step(self._h))
+
     def progress(self):
         ply, epi = self._buf((self.n,), torch.int32), self._buf((self.n,), torch.int32)
         _capi.check(self._lib.bgamd_env_get_progress(self._h, _ptr(ply), _ptr(epi), _stream()), "get_progress")
@@ -414,6 +432,7 @@ class Game:
             # where the host-argument surface (bgamd_game_*) runs: a caller inside `with torch.cuda.stream(s)` must not see
             # the reset overtake the set_state that follows
             self._v = pool.pop()
+            self._order()                # ... and not overtake what THIS thread still has queued on its current stream either
             self._v.reseed(_seed, _next_scalar_id, 1 << 40, null_stream=True)
             _capi.check(self._v._lib.bgamd_env_reset_stats(self._v._h, None), "reset_stats")
         else:
@@ -428,6 +447,10 @@ class Game:
         v = getattr(self, "_v", None)
         if v is not None and getattr(v, "_h", None) and _POOL is not None:
             self._v = None
+            try:                                             # work the dying Game queued on a side stream (make_move's step) must be done
+                self._order()                                # before the env's next owner resets it on the NULL stream
+            except Exception:
+                pass
             pool = _POOL.setdefault(v.device.index or 0, [])
             if len(pool) < 64:
                 pool.append(v)

@@ -64,6 +64,8 @@ SYMBOLS = [
     ("bgamd_env_unique_rows_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
     ("bgamd_env_set_trajectory", C.c_int, [_P, _P, C.c_int64]),
     ("bgamd_env_get_progress", C.c_int, [_P, _P, _P, _P]),
+    ("bgamd_env_set_trajectory_ring", C.c_int, [_P, _P, C.c_int64, _P]),
+    ("bgamd_env_trajectory_step", C.c_int64, [_P]),
     ("bgamd_encode_rows", C.c_int, [_P, C.c_int64, _P, _P]),
     ("bgamd_encode", C.c_int, [_P, _P, C.c_int64, _P, _P]),
     ("bgamd_evaluate", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P]),
@@ -79,9 +81,15 @@ SYMBOLS = [
     ("bgamd_td_begin", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P]),
     ("bgamd_td_stream_schedule", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("bgamd_td_begin_stream", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P, _P, _P]),
+    ("bgamd_td_begin_stream_games", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     ("bgamd_td_step", C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, C.c_float, _P, _P]),
     ("bgamd_td_apply", C.c_int, [_P, _P, _P]),
     ("bgamd_td_replay", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_double, C.c_float, _P]),
+    ("bgamd_td_comm_unique_id", C.c_int, [_P]),
+    ("bgamd_td_comm_init", C.c_int, [_P, _P, C.c_int, C.c_int]),
+    ("bgamd_td_comm_destroy", C.c_int, [_P]),
+    ("bgamd_td_step_allreduce", C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, C.c_float, _P]),
+    ("bgamd_td_replay_allreduce", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_double, C.c_float, _P]),
     ("bgamd_td_stats", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("bgamd_td_active_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("bgamd_td_written_columns", C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -218,6 +218,41 @@ class DeviceTDLambdaLearner:
     def _s(self):
         return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def init_collective(self, group=None):
+        """Gives the learner an RCCL communicator of its own (bgamd_td_comm_init) over the ranks of `group`: the per-step all-reduce of
+        a distributed replay is then issued by the library, on the learner's stream, between the step's kernels and the apply kernel
+        (bgamd_td_replay_allreduce) -- no torch dispatch per training step.  The 128-byte id travels through `group` (any backend).
+        A world of one rank gets a communicator too (what tools/train_dist_step.py measures)."""
+        C, lib, chk = self._C, self._lib, self._capi.check
+        rank, world = 0, 1
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_uint8 * 128)()
+        if rank == 0:
+            chk(lib.bgamd_td_comm_unique_id(buf), "td_comm_unique_id")
+        if world > 1:
+            cuda = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(buf), dtype=torch.uint8, device=self.device if cuda else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            buf = (C.c_uint8 * 128)(*t.cpu().tolist())
+        torch.cuda.synchronize(self.device)
+        chk(lib.bgamd_td_comm_init(self._h, buf, rank, world), "td_comm_init")
+        self._comm = (rank, world)
+
+    @staticmethod
+    def _world(group):
+        return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _distributed(self, group):
+        """the replay issues a collective per training step: more than one rank, or BGAMD_FORCE_COLLECTIVE=1 on a world of one (what
+        tools/train_dist_step.py and the world-1 test measure: the cost of the call with the communicator present)"""
+        forced = os.environ.get("BGAMD_FORCE_COLLECTIVE") == "1"
+        return self._world(group) > 1 or (forced and ((dist.is_available() and dist.is_initialized()) or getattr(self, "_comm", None) is not None))
+
+    def _in_library(self, distributed):
+        """the library's own collective serves this replay: the learner has a communicator and the replay is a distributed one"""
+        return distributed and getattr(self, "_comm", None) is not None and os.environ.get("BGAMD_TD_TORCH_COLLECTIVE") != "1"
+
     def set_weights(self, weights_flat):
         w = torch.as_tensor(weights_flat, dtype=torch.float32).flatten().to(self.device).contiguous()
         if w.numel() != 25601:
@@ -283,15 +318,14 @@ class DeviceTDLambdaLearner:
         n_games = int((sl > 0).sum().item())
         # BGAMD_FORCE_COLLECTIVE=1: issue the per-step all-reduce on a group of ONE rank too (tools/train_dist_step.py measures what the
         # collective's launch costs a training step with the RCCL communicator present; more ranks are the driver's to launch)
-        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
-                                                                         os.environ.get("BGAMD_FORCE_COLLECTIVE") == "1")
+        distributed = self._distributed(group)
         if slots and slots > 0:
             return self._replay_stream(rows, T, n, lengths, won, order[:n_games], sl[:n_games], int(slots), group, distributed,
                                        batch_scale, split_apply)
         n_sub = 1
         if sub_round and sub_round > 0:
             n_sub = max(1, -(-n_games // int(sub_round)))
-        if distributed:                                         # every rank runs the same number of sub-rounds
+        if distributed and self._world(group) > 1:              # every rank runs the same number of sub-rounds
             ns = torch.tensor([n_sub], dtype=torch.int64, device=self.device)
             dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)
             n_sub = int(ns.item())
@@ -303,6 +337,67 @@ class DeviceTDLambdaLearner:
             sq_tot += sq
             cnt_tot += cnt
         return sq_tot, cnt_tot
+
+    def replay_games(self, ring_rows, game_lane, game_start, lengths, p1_won, slots: int, group=None, batch_scale: float = 1.0):
+        """Streamed replay over a GAME TABLE and a ring log (continuous self-play: VecGame.record_ring, ContinuousSelfPlay.finished):
+        game i sits in column game_lane[i] of ring_rows [R, n, 8], its turn k in ring slot (game_start[i] + k) % R, lengths / p1_won are
+        per game.  The same schedule, kernels and arithmetic as replay_rows(slots=k): a table with one game per lane starting in slot 0
+        IS replay_rows.  Returns (Σ δ², number of (game, step) updates)."""
+        C, lib, chk = self._C, self._lib, self._capi.check
+        ring_rows = ring_rows.contiguous()
+        R, n = int(ring_rows.shape[0]), int(ring_rows.shape[1])
+        lane = torch.as_tensor(game_lane, device=self.device).to(torch.int32).contiguous()
+        start = torch.as_tensor(game_start, device=self.device).to(torch.int32).contiguous()
+        lengths = torch.as_tensor(lengths, device=self.device).to(torch.int32).contiguous()
+        won = torch.as_tensor(p1_won, device=self.device).to(torch.uint8).contiguous()
+        G = int(lengths.numel())
+        if not (lane.numel() == start.numel() == won.numel() == G):
+            raise ValueError("game table columns differ in length")
+        if G and int(lengths.max().item()) > R:
+            raise ValueError("a game is longer than the ring log")
+        distributed = self._distributed(group)
+        h_len = lengths.cpu().numpy().astype(np.int32, copy=False) if G else np.zeros(1, dtype=np.int32)
+        k = max(1, min(int(slots), self.max_games))
+        h_queue, h_qoff = np.zeros(max(G, 1), dtype=np.int32), np.zeros(k + 1, dtype=np.int32)
+        ng, nst = C.c_int64(), C.c_int64()
+        chk(lib.bgamd_td_stream_schedule(h_len.ctypes.data, G, k, h_queue.ctypes.data, h_qoff.ctypes.data, C.byref(ng), C.byref(nst)),
+            "td_stream_schedule")
+        k = min(k, int(ng.value))
+        n_steps = int(nst.value)
+        queue = torch.from_numpy(h_queue[:max(int(ng.value), 1)]).to(self.device)
+        qoff = torch.from_numpy(h_qoff[:k + 1]).to(self.device)
+        if G == 0:                                                   # (a rank without finished games still joins the collectives below)
+            lane = start = lengths = torch.zeros(1, dtype=torch.int32, device=self.device)
+            won = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        self._keep = (ring_rows, lane, start, lengths, won, queue, qoff)
+        chk(lib.bgamd_td_begin_stream_games(self._h, self._p(ring_rows), R, n, self._p(queue), self._p(qoff), k, max(G, 1), self._p(lane),
+                                            self._p(start), self._p(lengths), self._p(won), self._s()), "td_begin_stream_games")
+        alpha = float(self.learning_rate) * float(batch_scale)
+        lam = float(self.lambda_decay)
+        if not distributed:
+            arr = (C.c_int64 * max(n_steps, 1))(*([k] * n_steps))
+            chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
+        else:
+            ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            if self._world(group) > 1:
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)
+            if self._in_library(True):
+                own = n_steps if G else 0
+                arr = (C.c_int64 * max(own, 1))(*([k] * own))
+                chk(lib.bgamd_td_replay_allreduce(self._h, int(ns.item()), arr, own, alpha, lam, self._s()), "td_replay_allreduce")
+            else:
+                upd = torch.zeros(25601, dtype=torch.float32, device=self.device)
+                for t in range(int(ns.item())):
+                    if G and t < n_steps:
+                        chk(lib.bgamd_td_step(self._h, t, k, alpha, lam, self._p(upd), self._s()), "td_step")
+                    else:
+                        upd.zero_()
+                    dist.all_reduce(upd, op=dist.ReduceOp.SUM, group=group)
+                    chk(lib.bgamd_td_apply(self._h, self._p(upd), self._s()), "td_apply")
+        sq, cnt = C.c_double(), C.c_int64()
+        chk(lib.bgamd_td_stats(self._h, C.byref(sq), C.byref(cnt)), "td_stats")
+        self._keep = None
+        return float(sq.value), int(cnt.value)
 
     def _replay_stream(self, rows, T, n, lengths, won, order, sl, slots, group, distributed, batch_scale, split_apply):
         """Streamed replay (bgamd_td_begin_stream): order = lanes by decreasing length sl."""
@@ -327,6 +422,13 @@ class DeviceTDLambdaLearner:
         if not distributed and not split_apply:
             arr = (C.c_int64 * max(n_steps, 1))(*([k] * n_steps))
             chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
+        elif self._in_library(distributed):
+            ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            if self._world(group) > 1:
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)      # every rank issues the same collectives
+            own = n_steps if n_games else 0
+            arr = (C.c_int64 * max(own, 1))(*([k] * own))
+            chk(lib.bgamd_td_replay_allreduce(self._h, int(ns.item()), arr, own, alpha, lam, self._s()), "td_replay_allreduce")
         else:
             ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
             if distributed:
@@ -363,6 +465,12 @@ class DeviceTDLambdaLearner:
         if not distributed and not split_apply:
             arr = (C.c_int64 * max(n_steps, 1))(*n_active)
             chk(lib.bgamd_td_replay(self._h, n_steps, arr, alpha, lam, self._s()), "td_replay")
+        elif self._in_library(distributed):
+            ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            if self._world(group) > 1:
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)      # every rank issues the same collectives
+            arr = (C.c_int64 * max(n_steps, 1))(*n_active)
+            chk(lib.bgamd_td_replay_allreduce(self._h, int(ns.item()), arr, n_steps, alpha, lam, self._s()), "td_replay_allreduce")
         else:
             ns = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
             if distributed:
@@ -409,3 +517,55 @@ def play_round(env, max_plies: int = 512, epsilon: float = 0.0, precision=0, epi
     T = int(lengths.max().item()) if lengths.numel() else 0
     env.record_trajectory(None)
     return traj[:max(T, 1)], lengths, p1_won
+
+
+class ContinuousSelfPlay:
+    """Self-play without the tail: every lane starts its next game (the lane's next episode: fresh dice, fresh opening roll) the step
+    after its last one ended, so all n lanes are busy at every step, and the turns go to a RING log indexed by the env step
+    (VecGame.record_ring, bgamd_env_set_trajectory_ring).  A round of one game per lane (play_round: train.py:527-547 as it stands) spends
+    most of its ~460 steps on a few long games; here 65 536 lanes finish ~65 536 games every ~84 steps.  Every game is still ONE episode
+    of ONE lane -- with fixed weights the same game play_round(episode=k) plays (tests/test_gpu_round4.py) -- but a caller that refreshes
+    the weights between windows lets the games in flight go on under the new ones: the documented deviation of this mode (TD-Gammon's own
+    self-play changes the weights after every move).
+
+        sp = ContinuousSelfPlay(env, ring_steps=1024)
+        sp.play(84, epsilon=0.1)                      # 84 env steps, all lanes
+        table = sp.finished()                          # the games that ended in those steps
+        learner.replay_games(sp.rows, *table, slots=2048)
+    """
+
+    def __init__(self, env, ring_steps: int = 1024, episode: int = 0):
+        self.env = env
+        self.R = int(ring_steps)
+        self.rows, self.end = env.record_ring(self.R)
+        env.reset(episode=int(episode))
+        self._collected = 0                        # env steps whose end records finished() has turned into games
+
+    def play(self, n_steps: int, epsilon: float = 0.0, precision=0):
+        if self.env.trajectory_step() + int(n_steps) - self._collected > self.R:
+            raise ValueError("the window is longer than the ring: collect finished() first")
+        self.env.run_greedy(int(n_steps), auto_reset=True, epsilon=epsilon, precision=precision)
+
+    def finished(self, keep_margin: int = 0):
+        """The games that ended in the env steps played since the last call -> (game_lane, game_start, lengths, p1_won) device tensors,
+        in (end step, lane) order.  A game whose first turns the ring has already overwritten -- longer than ring_steps - window -
+        keep_margin (keep_margin: env steps that will be PLAYED while this table is replayed, i.e. the next window of a pipelined
+        loop) -- is dropped and counted in .dropped."""
+        s0, s1 = self._collected, self.env.trajectory_step()
+        self._collected = s1
+        if s1 - s0 > self.R:
+            raise ValueError("more steps played than the ring holds")
+        steps = torch.arange(s0, s1, device=self.rows.device)
+        rec = self.end[steps % self.R]                               # [window, n] int16
+        k, lane = torch.nonzero(rec, as_tuple=True)
+        val = rec[k, lane].to(torch.int32)
+        length = val & 0x7FFF
+        won = val >= 0                                               # bit 15 = winner (1 = PLAYER2): a negative int16
+        first = s0 + k.to(torch.int64) - length.to(torch.int64) + 1  # env step of the game's first turn
+        ok = (first >= 0) & (first > s1 + int(keep_margin) - 1 - self.R)
+        self.dropped = int((~ok).sum().item())
+        lane, length, won, first = lane[ok], length[ok], won[ok], first[ok]
+        return lane.to(torch.int32), (first % self.R).to(torch.int32), length.to(torch.int32), won
+
+    def close(self):
+        self.env.record_ring(None)

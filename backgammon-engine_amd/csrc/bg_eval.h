@@ -799,10 +799,12 @@ struct TrajRowsFetch {
     const uint4 *rows; const int4 *gmeta; long long t, n_lanes, T;
     __device__ __forceinline__ bool get(long long R, uint4 &u0, uint4 &u1) const
     {
-        const int4 gm = gmeta[R >> 1];                            // (lane, length, p1_won, the step the game started at)
+        const int4 gm = gmeta[R >> 1];                            // (lane, length, p1_won | first log row << 1, the step the game started at)
         const long long tt = t - gm.w + (R & 1);
         if (tt >= gm.y || tt >= T) return false;
-        const uint4 *src = rows + (tt * n_lanes + gm.x) * 2;
+        long long lr = tt + (gm.z >> 1);                          // a ring log (streamed replay of continuous self-play): first row != 0
+        if (lr >= T) lr -= T;
+        const uint4 *src = rows + (lr * n_lanes + gm.x) * 2;
         u0 = src[0]; u1 = src[1];
         return true;
     }

@@ -83,11 +83,15 @@ struct TdView {
     const int32_t *order;                // [n_games] lane index, by decreasing length
     const int32_t *length;               // [n_lanes]
     const uint8_t *p1_won;               // [n_lanes]
-    int4 *gmeta;                         // [max_games] (lane, length, p1_won, start step) of the game in slot i: one load, no chain
+    int4 *gmeta;                         // [max_games] (lane, length, p1_won | log row of the first turn << 1, start step) of the game in slot i: one load, no chain
     // streamed replay (bgamd_td_begin_stream): slot i plays the games queue[qoff[i] .. qoff[i + 1]) one after another; qcur[i] = the
     // next one.  Lock-step replay: one game per slot, all starting at step 0 (queue == nullptr).
     const int32_t *queue, *qoff;
     int32_t *qcur;
+    // game table of a streamed replay over a RING log (bgamd_td_begin_stream_games): queue entries are game ids; game id -> the lane whose
+    // column of the log holds it and the ring slot of its first turn.  nullptr: game id = lane, first turn in row 0 (one game per lane).
+    const int32_t *game_lane, *game_start;
+    long long n_table;                   // entries of length / p1_won (and of the game table)
     unsigned int *nupd;                  // [max_games] (game, step) updates of the slot since begin
     uint16_t *wl3;                       // fc1.weight as three bf16 planes in the MFMA layout of bg_eval.h (refreshed with every update)
     uint2 *lut;                          // count -> 4 bf16 features
@@ -162,22 +166,33 @@ __global__ void td_gather_kernel(TdView v)
 // (length 0: a lock-step replay, or the queue is used up).
 __device__ __forceinline__ void td_advance_slot(const TdView &v, long long i, int start)
 {
-    int lane = 0, len = 0, won = 0;
+    int lane = 0, len = 0, won = 0, first_row = 0;
     if (v.queue) {
         int c = v.qcur[i];
         const int end = v.qoff[i + 1];
         while (c < end && len == 0) {
-            lane = v.queue[c++];
+            int id = v.queue[c++];                           // caller data: kept inside the tables whatever it says
+            id = id < 0 ? 0 : (id >= v.n_table ? (int)v.n_table - 1 : id);
+            lane = v.game_lane ? v.game_lane[id] : id;
             lane = lane < 0 ? 0 : (lane >= v.n_lanes ? (int)v.n_lanes - 1 : lane);
-            len = v.length[lane];
+            len = v.length[id];
             len = len < 0 ? 0 : (len > v.T ? (int)v.T : len);
-            won = v.p1_won[lane] ? 1 : 0;
+            won = v.p1_won[id] ? 1 : 0;
+            first_row = v.game_start ? v.game_start[id] : 0;
+            first_row = first_row < 0 ? 0 : (first_row >= v.T ? (int)v.T - 1 : first_row);
         }
         v.qcur[i] = c;
     }
     int4 gm;
-    gm.x = len ? lane : 0; gm.y = len; gm.z = len ? won : 0; gm.w = start;
+    gm.x = len ? lane : 0; gm.y = len; gm.z = len ? (won | (first_row << 1)) : 0; gm.w = start;
     v.gmeta[i] = gm;
+}
+
+// log row of a game's step tl (the log is a ring of T rows when the game table names a first row; tl < length <= T)
+__device__ __forceinline__ long long td_log_row(const int4 &gm, long long tl, long long T)
+{
+    const long long r = tl + (gm.z >> 1);
+    return r >= T ? r - T : r;
 }
 
 __global__ void td_gather_stream_kernel(TdView v)
@@ -232,16 +247,17 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
         const long long i = i0 + g;
         bool live = i < n_active;
         int lane = 0;
-        long long tl = 0;                                 // the game's own step
+        long long tl = 0, lrow = 0;                       // the game's own step, its row of the log
         if (live && (!PRE || (s == 0 && c == 0))) {
             const int4 gm = v.gmeta[i];
             lane = gm.x;
             tl = t - gm.w;
             live = (tl + s) < gm.y && (tl + s) < v.T;     // s_{t+1} does not exist on the terminal step
+            lrow = td_log_row(gm, tl + s, v.T);
         } else if (PRE) live = false;                     // the matrix-pipe pass has decoded the rows: only s_t is needed here, once
         uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
-            const uint4 *src = v.rows + ((tl + s) * v.n_lanes + lane) * 2;
+            const uint4 *src = v.rows + (lrow * v.n_lanes + lane) * 2;
             const uint4 u0 = src[0], u1 = src[1];
             p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
         }
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(128) void td_forward_kernel(TdView v, long long t, 
             const long long tl = t - gm.w;
             if (tl < gm.y) {
                 const float val = outs[tid], vnext = outs[TD_GB + tid];
-                const float z = gm.z ? 1.0f : 0.0f;
+                const float z = (gm.z & 1) ? 1.0f : 0.0f;
                 const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;   // lengths never exceed the log (host check)
                 g = val * (1.0f - val);
                 v.coef[i] = (float)(alpha * (double)delta);
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
     const float w20 = v.theta[TD_OFF_W2 + lane], w21 = v.theta[TD_OFF_W2 + lane + 64], b2 = v.theta[TD_OFF_B2];
     uint32_t old = 0;
     if (tl != 0 && lane < TD_FLAG_WORD) old = v.amask[i * TD_MASK_WORDS + lane];
-    const uint4 *src = v.rows + (tl * v.n_lanes + gm.x) * 2;   // s_t exists for every running game
+    const uint4 *src = v.rows + (td_log_row(gm, tl, v.T) * v.n_lanes + gm.x) * 2;   // s_t exists for every running game
     const uint4 u0 = src[0], u1 = src[1];
     const uint32_t row[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
     const float h0 = td_sigmoid(a0), h1 = td_sigmoid(a1), k0 = td_sigmoid(c0), k1 = td_sigmoid(c1);
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(256) void td_epilogue_wave_kernel(TdView v, long lo
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { sv += __shfl_xor(sv, m, 64); sn += __shfl_xor(sn, m, 64); }
     const float val = td_sigmoid(sv + b2), vnext = td_sigmoid(sn + b2);
-    const float z = gm.z ? 1.0f : 0.0f;
+    const float z = (gm.z & 1) ? 1.0f : 0.0f;
     const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
     const float g = val * (1.0f - val);
     float *f = v.fac + i * TD_FLD;
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(ROOT3D_THREADS) void td_forward_mfma_kernel(TdView 
             const long long tl = t - gm.w;
             if (tl < gm.y) {
                 const float val = outs[2 * tid], vnext = outs[2 * tid + 1];
-                const float z = gm.z ? 1.0f : 0.0f;
+                const float z = (gm.z & 1) ? 1.0f : 0.0f;
                 const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
                 g = val * (1.0f - val);
                 v.coef[i] = (float)(alpha * (double)delta);
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v
                 const long long tl = t - gm.w;
                 if (tl < gm.y) {
                     const float val = outs[2 * tid], vnext = outs[2 * tid + 1];
-                    const float z = gm.z ? 1.0f : 0.0f;
+                    const float z = (gm.z & 1) ? 1.0f : 0.0f;
                     const float delta = (tl + 1 >= gm.y) ? z - val : vnext - val;
                     g = val * (1.0f - val);
                     cf = (float)(alpha * (double)delta);

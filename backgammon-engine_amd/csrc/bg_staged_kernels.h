@@ -99,8 +99,9 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
             while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.f[baseF + offF++] = Node{gg, key_child(1u << KEY_PASS_SHIFT, o)}; }
         }
         if (flags & BGAMD_ROLL) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
-        if (e.traj && (long long)c.ply < e.traj_plies) {        // trajectory log: 32 B per turn instead of 792 B
-            const unsigned long long t = ((unsigned long long)c.ply * (unsigned long long)e.n + (unsigned long long)g) * 2;
+        const long long lrow = e.traj_ring ? e.log_slot : (long long)c.ply;      // ring log: by env step; else by the lane's ply
+        if (e.traj && lrow < e.traj_plies) {                    // trajectory log: 32 B per turn instead of 792 B
+            const unsigned long long t = ((unsigned long long)lrow * (unsigned long long)e.n + (unsigned long long)g) * 2;
             e.traj[t] = make_uint4(c.p[0] | (c.turn ? TURN_BIT : 0u), c.p[1], c.p[2], c.p[3]);
             e.traj[t + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
         }

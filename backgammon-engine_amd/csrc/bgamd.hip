@@ -16,6 +16,8 @@
 #include <vector>
 #include <queue>
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is resolved at run time (rccl_api below), libbgamd.so does not link it
 
 #include "../../include/bgamd.h"
 #include "bg_board.h"
@@ -58,6 +60,12 @@ struct EnvView {
     unsigned long long *counters;
     uint4 *traj;               // optional [max_plies][n][2]: pre-move row of every turn (train.py:105-106)
     long long traj_plies;
+    // ring log of continuous self-play (bgamd_env_set_trajectory_ring): traj is [traj_ring][n][2] indexed by the ENV STEP (mod traj_ring),
+    // not by the lane's ply -- a lane's column holds game after game -- and endrec[slot][lane] says whether the game whose turn was
+    // logged in that slot ended with it: 0, or logged turns of the game | winner << 15.  log_slot / end_slot: the slots the roots /
+    // the apply of THIS launch write (set by the host per launch).
+    unsigned short *endrec;
+    long long traj_ring, log_slot, end_slot;
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int turn, int d1, int d2, bool fin)
@@ -96,6 +104,8 @@ __device__ __forceinline__ void finish_turn(const EnvView &e, long long g, uint3
     uint32_t oflags = 0;
     bool fin = false;
     const int oc = live ? over_code(p) : 0;
+    if (e.endrec && g < e.n)                               // ring log: did the game whose turn sits in this step's slot end with it?
+        e.endrec[e.end_slot * e.n + g] = oc ? (unsigned short)((ply + 1u > 0x7FFFu ? 0x7FFFu : ply + 1u) | ((uint32_t)(oc - 1) << 15)) : (unsigned short)0;
     if (oc) {
         oflags = 1u | ((uint32_t)(oc - 1) << 1);
         if (flags & BGAMD_AUTO_RESET) {
@@ -643,6 +653,11 @@ struct bgamd_env {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   //   (fork after roots_kernel, join before the incremental kernel)
 
     unsigned long long *tops_base = nullptr;   // [2][T_COUNT]; sv.tops points at the set of the last step
+    // ring log of continuous self-play (bgamd_env_set_trajectory_ring): greedy steps log by env step; traj_step counts the steps logged
+    uint4 *ring_rows = nullptr;
+    unsigned short *ring_end = nullptr;
+    long long ring_steps = 0;
+    long long traj_step = 0;
     int32_t *d_scalar = nullptr;           // device staging of the scalar (host-argument) surface: args at [0..63], results behind
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
@@ -1275,6 +1290,8 @@ struct GreedyRun {
     float epsilon;
     bool incremental;
     StagedView sv;
+    EnvView ev;                            // the env's view as this run's launches take it (ring log: the slots of the step at hand)
+    long long cur_step = 0;                // ring log: the env step being played
     const float *b1, *w2, *b2;
 
     int init(bgamd_env *e, int fl, float eps, int prec)
@@ -1288,7 +1305,18 @@ struct GreedyRun {
         sv = env->sv;
         sv.tops = env->tops_base;
         parity = 0;
+        ev = env->v;
+        if (env->ring_rows) {
+            ev.traj = env->ring_rows; ev.traj_plies = env->ring_steps; ev.traj_ring = env->ring_steps; ev.endrec = env->ring_end;
+        }
         return BGAMD_OK;
+    }
+    // ring log: the roots about to be launched log env step traj_step (the step they begin)
+    void next_log_slot()
+    {
+        if (!ev.traj_ring) return;
+        cur_step = env->traj_step++;
+        ev.log_slot = cur_step % ev.traj_ring;
     }
     dim3 egrid(long long max_items, int mode, int n_cu) const    // expand_kernel: 48 B of LDS per thread, 2 048 threads per CU
     {
@@ -1305,7 +1333,8 @@ struct GreedyRun {
     {
         HIPCHK(hipMemsetAsync(env->tops_base, 0, 2 * T_COUNT * 8, s));
         KTimer t(env, s, 4);
-        hipLaunchKernelGGL(roots_kernel, grid1(env->v.n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
+        next_log_slot();
+        hipLaunchKernelGGL(roots_kernel, grid1(env->v.n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, flags);
         return BGAMD_OK;
     }
     int step(const StepStreams &ss, bool more)
@@ -1346,11 +1375,11 @@ struct GreedyRun {
         }
         {
             KTimer t(env, s, 4);
-            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, ev, sv);
         }
         {
             KTimer t(env, s, 5);
-            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, env->v, sv);
+            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, ev, sv);
         }
         const bool fused = more && incremental;                // the dense kernels do not clear the other counter set
         StagedView sv_next = sv;
@@ -1384,24 +1413,27 @@ struct GreedyRun {
         if (epsilon > 0.0f) {                              // exploring lanes pick through their counted tasks (bounded work)
             KTimer t(env, s, 3);
             HIPCHK(hipMemsetAsync(env->rv.top, 0, 8, s));
-            hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, env->v, env->rv, flags & ~BGAMD_ROLL, epsilon);
+            hipLaunchKernelGGL(rnd_tasks_kernel, grid1(n, 256), dim3(256), 0, s, ev, env->rv, flags & ~BGAMD_ROLL, epsilon);
             long long b = (n * 4 + 255) / 256;
             const long long lim = (long long)ss.n_cu * 8;
-            hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, env->v, env->rv);
+            hipLaunchKernelGGL(rnd_count_kernel, dim3((unsigned)(b > lim ? lim : b)), dim3(256), 0, s, ev, env->rv);
         }
         {
             KTimer t(env, s, 2);
-            if (fused)
-                hipLaunchKernelGGL(boundary_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, sv_next, xv, flags, epsilon);
-            else
-                hipLaunchKernelGGL(apply_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, xv, flags, epsilon);
+            ev.end_slot = ev.traj_ring ? cur_step % ev.traj_ring : 0;      // the apply half closes the step the last roots began
+            if (fused) {
+                next_log_slot();                                           // ... and the roots half begins the next one
+                hipLaunchKernelGGL(boundary_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, sv_next, xv, flags, epsilon);
+            } else
+                hipLaunchKernelGGL(apply_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, xv, flags, epsilon);
         }
         env->sv.tops = sv.tops;                                // the set whose T_U describes the last evaluated rows
         if (fused) { parity ^= 1; sv = sv_next; }
         else if (more) {                                       // dense value-net modes: plain per-step sequence
             HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
             KTimer t(env, s, 4);
-            hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, env->v, sv, flags);
+            next_log_slot();
+            hipLaunchKernelGGL(roots_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, flags);
         }
         return BGAMD_OK;
     }
@@ -1520,6 +1552,19 @@ int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies)
     env->v.traj_plies = d_rows ? max_plies : 0;
     return BGAMD_OK;
 }
+
+int bgamd_env_set_trajectory_ring(bgamd_env *env, void *d_rows, int64_t ring_steps, uint16_t *d_end)
+{
+    if (!env || (d_rows && (ring_steps <= 0 || !d_end))) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(env->device));
+    env->ring_rows = (uint4 *)d_rows;
+    env->ring_end = d_rows ? (unsigned short *)d_end : nullptr;
+    env->ring_steps = d_rows ? ring_steps : 0;
+    env->traj_step = 0;
+    return BGAMD_OK;
+}
+
+int64_t bgamd_env_trajectory_step(const bgamd_env *env) { return env ? env->traj_step : 0; }
 
 int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, void *stream)
 {
@@ -1686,6 +1731,13 @@ struct bgamd_td {
     bool lazy = true;                      // lazily scaled traces (bg_learner.h); BGAMD_TD_LAZY=0: e <- λ e + ∇ every step
     double scale = 1.0;                    // c: stored trace = e / c, the same for every game of the replay
     bool stream_mode = false;              // bgamd_td_begin_stream: slots take game after game, steps are not bounded by the log length
+    hipStream_t last_stream = nullptr;     // the stream the replay at hand is issued on: what the readers below wait for (a learner replaying on
+                                           //   its own stream beside an env at play must not wait for the env: no device-wide synchronisation)
+    // the ONE collective of a multi-rank training step issued by the library: an RCCL communicator of the learner's own (bgamd_td_comm_init)
+    void *rccl = nullptr;                  // dlopen handle of librccl.so.1 (the one already in the process when there is one)
+    void *comm = nullptr;                  // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    float *d_upd = nullptr;                // [TD_P] the step's update, all-reduced in place
     bool timing = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -1694,6 +1746,12 @@ struct bgamd_td {
 };
 
 namespace {
+// device -> host on the replay's own stream (never the null stream: a learner beside an env at play waits for its own work only)
+hipError_t td_read(bgamd_td *td, void *dst, const void *src, size_t bytes)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, td->last_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(td->last_stream);
+}
 int td_flush(bgamd_td *td)
 {
     for (size_t i = 0; i < td->ev_used; ++i) {
@@ -1790,6 +1848,8 @@ int bgamd_td_destroy(bgamd_td *td)
     void *ptrs[] = {v.theta, v.w1t, v.e, v.fac, v.coef, v.sq, v.partial, v.gmeta, v.amask, v.anew, v.act_cols, v.wr_cols, v.nupd, v.qcur, v.wl3, v.lut, v.hid};
     for (void *p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
+    bgamd_td_comm_destroy(td);
+    if (td->d_upd) hipFree(td->d_upd);
     delete td;
     return BGAMD_OK;
 }
@@ -1827,6 +1887,8 @@ int bgamd_td_begin(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes,
     v.p1_won = d_p1_won;
     v.T = T; v.n_lanes = n_lanes; v.n_games = n_games;
     v.queue = nullptr; v.qoff = nullptr;
+    v.game_lane = nullptr; v.game_start = nullptr; v.n_table = n_lanes;
+    td->last_stream = (hipStream_t)stream;
     if (n_games > 0) {
         hipLaunchKernelGGL(td_gather_kernel, grid1(n_games, 256), dim3(256), 0, (hipStream_t)stream, v);
         HIPCHK(hipGetLastError());
@@ -1843,11 +1905,12 @@ int bgamd_td_stream_schedule(const int32_t *h_length, int64_t n_lanes, int64_t n
     return bg::td_stream_schedule(h_length, n_lanes, n_slots, h_queue, h_queue_offsets, h_n_games, h_n_steps) ? BGAMD_E_INVALID : BGAMD_OK;
 }
 
-int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
-                          const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
+static int td_begin_stream_impl(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
+                                const int32_t *d_queue_offsets, int64_t n_slots, int64_t n_table, const int32_t *d_game_lane,
+                                const int32_t *d_game_start, const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
 {
-    if (!td || !d_rows || !d_queue || !d_queue_offsets || !d_length || !d_p1_won || T <= 0 || n_lanes <= 0 || n_slots < 0 ||
-        n_slots > td->max_games)
+    if (!td || !d_rows || !d_queue || !d_queue_offsets || !d_length || !d_p1_won || T <= 0 || n_lanes <= 0 || n_table <= 0 || n_slots < 0 ||
+        n_slots > td->max_games || T > 0x3FFFFFFFll)
         return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
     TdView &v = td->v;
@@ -1857,13 +1920,30 @@ int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n
     v.p1_won = d_p1_won;
     v.T = T; v.n_lanes = n_lanes; v.n_games = n_slots;
     v.queue = d_queue; v.qoff = d_queue_offsets;
+    v.game_lane = d_game_lane; v.game_start = d_game_start; v.n_table = n_table;
     if (n_slots > 0) {
         hipLaunchKernelGGL(td_gather_stream_kernel, grid1(n_slots, 256), dim3(256), 0, (hipStream_t)stream, v);
         HIPCHK(hipGetLastError());
     }
     td->begun = true;
     td->stream_mode = true;
+    td->last_stream = (hipStream_t)stream;
     return BGAMD_OK;
+}
+
+int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
+                          const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
+{
+    return td_begin_stream_impl(td, d_rows, T, n_lanes, d_queue, d_queue_offsets, n_slots, n_lanes, nullptr, nullptr, d_length, d_p1_won, stream);
+}
+
+int bgamd_td_begin_stream_games(bgamd_td *td, const void *d_rows, int64_t ring_steps, int64_t n_lanes, const int32_t *d_queue,
+                                const int32_t *d_queue_offsets, int64_t n_slots, int64_t n_games, const int32_t *d_game_lane,
+                                const int32_t *d_game_start, const int32_t *d_length, const uint8_t *d_p1_won, void *stream)
+{
+    if (!d_game_lane || !d_game_start) return BGAMD_E_INVALID;
+    return td_begin_stream_impl(td, d_rows, ring_steps, n_lanes, d_queue, d_queue_offsets, n_slots, n_games, d_game_lane, d_game_start, d_length,
+                                d_p1_won, stream);
 }
 
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream)
@@ -1873,6 +1953,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     HIPCHK(hipSetDevice(td->device));
     if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
     hipStream_t s = (hipStream_t)stream;
+    td->last_stream = s;
     if (n_active == 0) {                 // nothing to add, but the caller's collective still needs a defined buffer
         if (d_update) HIPCHK(hipMemsetAsync(d_update, 0, (size_t)TD_P * 4, s));
         return BGAMD_OK;
@@ -2026,17 +2107,17 @@ int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates)
 {
     ENV_GUARD(td);
     HIPCHK(hipSetDevice(td->device));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(td->last_stream));
     if (h_sq_sum) {
         std::vector<double> sq((size_t)td->v.n_games);
-        if (!sq.empty()) HIPCHK(hipMemcpy(sq.data(), td->v.sq, sq.size() * 8, hipMemcpyDeviceToHost));
+        if (!sq.empty()) HIPCHK(td_read(td, sq.data(), td->v.sq, sq.size() * 8));
         double acc = 0;
         for (double x : sq) acc += x;
         *h_sq_sum = acc;
     }
     if (h_updates) {
         std::vector<unsigned int> c((size_t)td->v.n_games);
-        if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.nupd, c.size() * 4, hipMemcpyDeviceToHost));
+        if (!c.empty()) HIPCHK(td_read(td, c.data(), td->v.nupd, c.size() * 4));
         int64_t tot = 0;
         for (unsigned int x : c) tot += x;
         *h_updates = tot;
@@ -2048,9 +2129,9 @@ int bgamd_td_active_columns(bgamd_td *td, uint64_t *h_columns)
 {
     if (!td || !h_columns) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(td->last_stream));
     std::vector<unsigned int> c((size_t)td->v.n_games);
-    if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.act_cols, c.size() * 4, hipMemcpyDeviceToHost));
+    if (!c.empty()) HIPCHK(td_read(td, c.data(), td->v.act_cols, c.size() * 4));
     uint64_t tot = 0;
     for (unsigned int x : c) tot += x;
     *h_columns = tot;
@@ -2061,17 +2142,18 @@ int bgamd_td_slots(bgamd_td *td, int32_t *h_out)
 {
     if (!td || !h_out) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(td->last_stream));
     const size_t n = (size_t)td->v.n_games;
     std::vector<int32_t> gm(4 * n), qc(n);
     std::vector<unsigned int> nu(n);
     if (n) {
-        HIPCHK(hipMemcpy(gm.data(), td->v.gmeta, n * 16, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(qc.data(), td->v.qcur, n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(nu.data(), td->v.nupd, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(td_read(td, gm.data(), td->v.gmeta, n * 16));
+        HIPCHK(td_read(td, qc.data(), td->v.qcur, n * 4));
+        HIPCHK(td_read(td, nu.data(), td->v.nupd, n * 4));
     }
     for (size_t i = 0; i < n; ++i) {
         for (int k = 0; k < 4; ++k) h_out[6 * i + k] = gm[4 * i + k];
+        h_out[6 * i + 2] &= 1;                                 // (the word also carries the game's first log row)
         h_out[6 * i + 4] = td->stream_mode ? qc[i] : -1;
         h_out[6 * i + 5] = (int32_t)nu[i];
     }
@@ -2082,9 +2164,9 @@ int bgamd_td_written_columns(bgamd_td *td, uint64_t *h_columns)
 {
     if (!td || !h_columns) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(td->last_stream));
     std::vector<unsigned int> c((size_t)td->v.n_games);
-    if (!c.empty()) HIPCHK(hipMemcpy(c.data(), td->v.wr_cols, c.size() * 4, hipMemcpyDeviceToHost));
+    if (!c.empty()) HIPCHK(td_read(td, c.data(), td->v.wr_cols, c.size() * 4));
     uint64_t tot = 0;
     for (unsigned int x : c) tot += x;
     *h_columns = tot;
@@ -2108,6 +2190,134 @@ int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint6
     if (h_launches) *h_launches = td->trace_launches;
     if (h_game_steps) *h_game_steps = td->trace_game_steps;
     td->trace_ms = 0; td->trace_launches = 0; td->trace_game_steps = 0;
+    return BGAMD_OK;
+}
+
+// ---- the ONE collective of a multi-rank training step, issued by the library -----------------------------------------------
+// one all-reduce (sum) of the 25 601-float update per training step, in place, on the compute stream.  Rounds 1-3 drove
+// it from Python (bgamd_td_step -> torch.distributed.all_reduce -> bgamd_td_apply): 9.5 us of host time per step for the dispatch
+// alone.  Here the learner owns an RCCL communicator and a step is three enqueues from C on ONE stream: the step's kernels with the
+// update handed out, ncclAllReduce in place, the apply kernel.  RCCL is resolved at run time -- the librccl.so.1 that is already in the
+// process (PyTorch brings its own) or the one of the ROCm install -- so libbgamd.so has no link-time dependency on it.
+}  // extern "C"
+
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.h ? &api : nullptr;
+    tried = true;
+    const char *names[] = {getenv("BGAMD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)                              // the copy that is already loaded wins: two RCCLs in one process is one too many
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : names)
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { g_hip_err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return nullptr; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+        g_hip_err = "librccl: a symbol is missing";
+        return nullptr;
+    }
+    api.h = h;
+    return &api;
+}
+
+#define RCCLCHK(api, call)                                                                  \
+    do {                                                                                    \
+        ncclResult_t _r = (call);                                                           \
+        if (_r != ncclSuccess) {                                                            \
+            g_hip_err = std::string(#call) + ": " + (api)->GetErrorString(_r);              \
+            return BGAMD_E_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int bgamd_td_comm_unique_id(uint8_t h_id[128])
+{
+    if (!h_id) return BGAMD_E_INVALID;
+    RcclApi *api = rccl_api();
+    if (!api) return BGAMD_E_HIP;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    RCCLCHK(api, api->GetUniqueId(&id));
+    memcpy(h_id, &id, 128);
+    return BGAMD_OK;
+}
+
+int bgamd_td_comm_init(bgamd_td *td, const uint8_t h_id[128], int rank, int world)
+{
+    if (!td || !h_id || world < 1 || rank < 0 || rank >= world) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    RcclApi *api = rccl_api();
+    if (!api) return BGAMD_E_HIP;
+    bgamd_td_comm_destroy(td);
+    if (!td->d_upd) HIPCHK(hipMalloc((void **)&td->d_upd, (size_t)TD_P * 4));
+    ncclUniqueId id;
+    memcpy(&id, h_id, 128);
+    ncclComm_t comm = nullptr;
+    RCCLCHK(api, api->CommInitRank(&comm, world, id, rank));
+    td->comm = comm; td->comm_rank = rank; td->comm_world = world;
+    return BGAMD_OK;
+}
+
+int bgamd_td_comm_destroy(bgamd_td *td)
+{
+    if (!td) return BGAMD_E_INVALID;
+    if (td->comm) {
+        RcclApi *api = rccl_api();
+        hipSetDevice(td->device);
+        hipDeviceSynchronize();
+        if (api) api->CommDestroy((ncclComm_t)td->comm);
+        td->comm = nullptr; td->comm_world = 0;
+    }
+    return BGAMD_OK;
+}
+
+int bgamd_td_step_allreduce(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, void *stream)
+{
+    if (!td || !td->comm || !td->d_upd) return BGAMD_E_INVALID;
+    HIPCHK(hipSetDevice(td->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n_active > 0) {
+        const int rc = bgamd_td_step(td, t, n_active, alpha, lambda, td->d_upd, stream);
+        if (rc) return rc;
+    } else {                                                 // this rank has nothing at step t: it still joins the collective
+        if (!td->has_weights) return BGAMD_E_NOWEIGHTS;
+        HIPCHK(hipMemsetAsync(td->d_upd, 0, (size_t)TD_P * 4, s));
+        td->last_stream = s;
+    }
+    RcclApi *api = rccl_api();
+    RCCLCHK(api, api->AllReduce(td->d_upd, td->d_upd, (size_t)TD_P, ncclFloat32, ncclSum, (ncclComm_t)td->comm, s));
+    hipLaunchKernelGGL(td_apply_kernel, grid1(TD_P, 256), dim3(256), 0, s, td->v, (const float *)td->d_upd, 0);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+
+int bgamd_td_replay_allreduce(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, int64_t n_own_steps, double alpha, float lambda,
+                              void *stream)
+{
+    if (!td || n_steps < 0 || n_own_steps < 0 || n_own_steps > n_steps || (n_own_steps > 0 && !h_n_active)) return BGAMD_E_INVALID;
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const int rc = bgamd_td_step_allreduce(td, t, t < n_own_steps ? h_n_active[t] : 0, alpha, lambda, stream);
+        if (rc != BGAMD_OK) return rc;
+    }
     return BGAMD_OK;
 }
 

@@ -36,6 +36,77 @@ def xavier_init(seed=0):
     return torch.cat([xu(128, 198).flatten(), torch.zeros(128), xu(1, 128).flatten(), torch.zeros(1)]).numpy()
 
 
+def run_continuous(a, env, arena, L, group, world, prec, say):
+    """--continuous [--pipeline-rounds]: windows of self-play on every lane, the games that ended in a window replayed streamed through
+    --slots; pipelined, window w is played while window w - 1 is replayed (learner on its own stream and host thread)."""
+    import threading
+    from backgammon_env.learner import ContinuousSelfPlay
+    assert a.slots > 0 and not a.host_learner, "--continuous replays streamed through --slots on the device learner"
+    dist = torch.distributed if world > 1 else None
+    sp = ContinuousSelfPlay(env, ring_steps=a.ring_steps)
+    side = torch.cuda.Stream()
+    dev = torch.cuda.current_device()
+    t0, turns, games_done, dropped = time.time(), 0, 0, 0
+    total_games = a.rounds * a.games * world          # ~ one game per lane and window once the lanes are out of step
+    res = {}
+
+    def replay(table, scale):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(side):
+            res["out"] = L.replay_games(sp.rows, *table, slots=a.slots, group=group, batch_scale=scale)
+
+    pending, th = None, None
+    for r in range(a.rounds + (1 if a.pipeline_rounds else 0)):
+        L.update_learning_params(games_done // max(1, a.schedule_div))
+        if a.lam is not None:
+            L.lambda_decay = a.lam
+        eps = a.eps if a.eps is not None else a.eps_start + (a.eps_end - a.eps_start) * min(1.0, games_done / total_games)
+        sg = a.scale_games if a.scale_warmup <= 0 else min(a.scale_games, a.scale_warmup * 2.0 ** r)
+        scale = min(1.0, sg / (a.slots * world))
+        env.load_weights(L.theta.cpu().numpy())        # the weights the last finished replay left
+        if a.pipeline_rounds and pending is not None:
+            th = threading.Thread(target=replay, args=(pending, scale))
+            th.start()
+        table = None
+        if r < a.rounds:
+            sp.play(a.window_steps, epsilon=eps, precision=prec)
+            table = sp.finished(keep_margin=a.window_steps if a.pipeline_rounds else 0)
+            dropped += sp.dropped
+            n_fin = torch.tensor([int(table[0].numel())], dtype=torch.int64, device="cuda")
+            if dist is not None and not a.pipeline_rounds:
+                dist.all_reduce(n_fin, group=group)
+            else:                                      # (pipelined: the learner's thread owns the process group while it replays -- two threads
+                n_fin *= world                         #  must not interleave collectives; every rank finishes ~ the same number of games)
+            games_done += int(n_fin.item())
+        if a.pipeline_rounds:
+            if th is not None:
+                th.join()
+                turns += res["out"][1]
+                th = None
+            pending = table
+        elif table is not None:
+            replay(table, scale)
+            side.synchronize()
+            turns += res["out"][1]
+        if r % 4 == 3 or r >= a.rounds - 1:
+            say(f"window {r + 1}: {games_done} games finished, td loss {res['out'][0] / max(1, res['out'][1]):.5f}, "
+                f"{world * turns / (time.time() - t0):.0f} turns/s" if res else f"window {r + 1}", flush=True)
+    torch.cuda.synchronize()
+    say(f"{games_done} games, {turns} turns replayed per rank in {time.time() - t0:.2f} s; {dropped} games dropped (longer than the ring allows)", flush=True)
+    w_after = L.theta.cpu().numpy()
+    if world > 1:
+        chk = torch.tensor([float(np.abs(w_after).sum()), -float(np.abs(w_after).sum())], dtype=torch.float64, device="cuda")
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=group)
+        assert chk[0].item() == -chk[1].item(), "replicas diverged"
+        say("replicas identical across", world, "ranks")
+    say("after: vs random", head_to_head(arena, w_after, None), flush=True)
+    ref = os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32")
+    if os.path.exists(ref):
+        say("after: vs tdgammonNEW100k", head_to_head(arena, w_after, np.fromfile(ref, dtype=np.float32)), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=512, help="games per round (one per lane)")
@@ -56,6 +127,15 @@ def main():
     ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
     ap.add_argument("--schedule-div", type=int, default=1, help="the reference's alpha / lambda schedule is a function of the episode count "
                     "(model.py:69-73, written for runs of ~1e5 episodes); it is evaluated at games_done // this")
+    ap.add_argument("--continuous", action="store_true", help="continuous self-play (learner.ContinuousSelfPlay): lanes restart their next game the step "
+                    "after the last one ended, turns go to a ring log by env step; a 'round' is --window-steps env steps of all lanes and the learner "
+                    "replays the games that ended in it (needs --slots).  Games in flight go on under the refreshed weights: a documented deviation")
+    ap.add_argument("--window-steps", type=int, default=84, help="env steps per window of --continuous (84 steps of n lanes ~ n finished games)")
+    ap.add_argument("--ring-steps", type=int, default=1024, help="depth of the ring log of --continuous (games longer than ring - 2 windows are dropped)")
+    ap.add_argument("--pipeline-rounds", action="store_true", help="with --continuous: the learner replays window w-1 on its own stream (and host "
+                    "thread) WHILE the env plays window w -- the self-play policy is one window staler than train.py:519-547's snapshot")
+    ap.add_argument("--in-library-collective", action="store_true", help="multi-rank: the per-step all-reduce is issued by the library on the "
+                    "learner's stream (bgamd_td_replay_allreduce, an RCCL communicator of the learner's own) instead of torch.distributed per step")
     ap.add_argument("--host-learner", action="store_true", help="PyTorch closed-form replay instead of the HIP kernels")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x2", "bf16"), default="auto",
@@ -85,7 +165,11 @@ def main():
         L = TDLambdaLearner(xavier_init(), device="cuda", alpha=0.1, lam=0.7)
     else:
         L = DeviceTDLambdaLearner(xavier_init(), max_games=a.games, alpha=0.1, lam=0.7)
+    if a.in_library_collective and not a.host_learner:
+        L.init_collective(group)
     say("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
+    if a.continuous:
+        return run_continuous(a, env, arena, L, group, world, prec, say)
     t0, turns = time.time(), 0
     total_games = a.rounds * a.games * world
     first_dice = None

@@ -209,6 +209,21 @@ int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, in
  * (a finished, frozen lane has ply = T-1).  bgamd_encode_rows: rows -> float[n][198]. */
 int bgamd_env_set_trajectory(bgamd_env *env, void *d_rows, int64_t max_plies);
 int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, void *stream);
+
+/* ---- ring log of CONTINUOUS self-play ---------------------------------------------------------------------------------
+ * play_game (train.py:64-121) plays one game to the end; a round of them (train.py:527-547) on n lanes ends with a long tail of
+ * nearly empty steps (mean game 83 turns, longest ~450: a 65 536-game round is ~460 steps for 5.5 M turns).  With BGAMD_AUTO_RESET a
+ * lane starts its next game (episode + 1 of the lane: fresh dice, fresh opening roll) the step after the last one ended, every lane
+ * is busy at every step, and the log is indexed by the ENV STEP instead of the lane's ply:
+ *   d_rows [ring_steps][n] x 32 B : the pre-move row of lane g at env step k (k counted from this call) sits in slot k % ring_steps
+ *   d_end  [ring_steps][n] uint16 : 0, or -- when the turn logged in that slot was the LAST of its game -- the game's number of logged
+ *                                   turns (<= 32 767) | winner << 15 (0 = PLAYER1).  The game's turns are the `turns` slots ending there.
+ * Only greedy steps (bgamd_env_step_greedy / run_greedy) log into the ring; every lane must take part in every step (no
+ * BGAMD_ONLY_P1/P2).  Every game is one episode of one lane: the same game bgamd_env_reset_episode + a run to the end plays with the
+ * same weights.  A caller that refreshes the weights between runs lets the games in flight go on under the new ones (TD-Gammon's own
+ * self-play changes the weights after every move).  NULL disables.  bgamd_env_trajectory_step: env steps logged since the call. */
+int bgamd_env_set_trajectory_ring(bgamd_env *env, void *d_rows, int64_t ring_steps, uint16_t *d_end);
+int64_t bgamd_env_trajectory_step(const bgamd_env *env);
 int bgamd_encode_rows(const void *d_rows, int64_t n, float *d_out198, void *stream);
 
 /* ---- stateless operators ----------------------------------------------------------------------
@@ -282,9 +297,31 @@ int bgamd_td_stream_schedule(const int32_t *h_length, int64_t n_lanes, int64_t n
 int bgamd_td_begin_stream(bgamd_td *td, const void *d_rows, int64_t T, int64_t n_lanes, const int32_t *d_queue,
                           const int32_t *d_queue_offsets, int64_t n_slots, const int32_t *d_length, const uint8_t *d_p1_won,
                           void *stream);
+/* The same over a GAME TABLE and a ring log (continuous self-play, bgamd_env_set_trajectory_ring): queue entries are game ids
+ * 0 .. n_games-1; game i sits in column d_game_lane[i] of the log, its first turn in ring slot d_game_start[i], its turn k in slot
+ * (d_game_start[i] + k) % ring_steps; d_length / d_p1_won are indexed by game id.  bgamd_td_stream_schedule takes d_length as it is. */
+int bgamd_td_begin_stream_games(bgamd_td *td, const void *d_rows, int64_t ring_steps, int64_t n_lanes, const int32_t *d_queue,
+                                const int32_t *d_queue_offsets, int64_t n_slots, int64_t n_games, const int32_t *d_game_lane,
+                                const int32_t *d_game_start, const int32_t *d_length, const uint8_t *d_p1_won, void *stream);
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream);
 int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream);
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream);
+/* ---- the one collective of a multi-rank training step, issued by the library ("one all-reduce of 25 601 fp32 per
+ * training step, RCCL over xGMI, in place, on the compute stream"; train.py:536-547 is the loop it scales).  The learner owns an RCCL
+ * communicator: rank 0 calls bgamd_td_comm_unique_id, the 128 bytes reach the other ranks by whatever the launcher has
+ * (torch.distributed broadcast, a file), every rank calls bgamd_td_comm_init (collective: returns when all ranks have).  RCCL is
+ * resolved at run time (the librccl.so.1 already in the process, else the ROCm install's; BGAMD_RCCL_LIB overrides).
+ *   step_allreduce  : bgamd_td_step with the update handed out -> ncclAllReduce(sum, in place) -> bgamd_td_apply, three enqueues on
+ *                     `stream`, no host synchronisation; n_active = 0: the rank adds nothing at step t but joins the collective
+ *   replay_allreduce: steps 0 .. n_steps-1 (the MAX over the ranks); this rank's own log covers the first n_own_steps of them */
+int bgamd_td_comm_unique_id(uint8_t h_id[128]);
+int bgamd_td_comm_init(bgamd_td *td, const uint8_t h_id[128], int rank, int world);
+int bgamd_td_comm_destroy(bgamd_td *td);
+int bgamd_td_step_allreduce(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, void *stream);
+int bgamd_td_replay_allreduce(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, int64_t n_own_steps, double alpha, float lambda,
+                              void *stream);
+/* (the readers below wait for the stream the replay was issued on, not for the device: a learner replaying on its own stream beside
+ * an env at play does not wait for the env) */
 int bgamd_td_stats(bgamd_td *td, double *h_sq_sum, int64_t *h_updates);
 /* Traffic report of the column-sparse traces: Σ over the (game, step) updates since begin of the W1 trace columns that
  * were touched (of 198; a column = 128 floats, read + written).  BGAMD_TD_DENSE=1 in the environment at bgamd_td_create
