@@ -36,17 +36,18 @@ def xavier_init(seed=0):
     return torch.cat([xu(128, 198).flatten(), torch.zeros(128), xu(1, 128).flatten(), torch.zeros(1)]).numpy()
 
 
-def run_continuous(a, env, arena, L, group, world, prec, say):
+def run_continuous(a, env, arena, L, group, world, prec, say, n_classic=0, t0=None, turns=0):
     """--continuous [--pipeline-rounds]: windows of self-play on every lane, the games that ended in a window replayed streamed through
     --slots; pipelined, window w is played while window w - 1 is replayed (learner on its own stream and host thread)."""
     import threading
     from backgammon_env.learner import ContinuousSelfPlay
     assert a.slots > 0 and not a.host_learner, "--continuous replays streamed through --slots on the device learner"
     dist = torch.distributed if world > 1 else None
-    sp = ContinuousSelfPlay(env, ring_steps=a.ring_steps)
+    sp = ContinuousSelfPlay(env, ring_steps=a.ring_steps, episode=n_classic)      # (the classic rounds played episodes 0 .. n_classic - 1)
     side = torch.cuda.Stream()
     dev = torch.cuda.current_device()
-    t0, turns, games_done, dropped = time.time(), 0, 0, 0
+    t0 = time.time() if t0 is None else t0
+    games_done, dropped = n_classic * a.games * world, 0
     total_games = a.rounds * a.games * world          # ~ one game per lane and window once the lanes are out of step
     res = {}
 
@@ -55,20 +56,27 @@ def run_continuous(a, env, arena, L, group, world, prec, say):
         with torch.cuda.stream(side):
             res["out"] = L.replay_games(sp.rows, *table, slots=a.slots, group=group, batch_scale=scale)
 
+    for b in range(a.burn_in_windows):                 # lanes out of step before the first window that counts (weights: the initial ones)
+        if b == 0:
+            env.load_weights(L.theta.cpu().numpy())
+        sp.play(a.window_steps, epsilon=a.eps if a.eps is not None else a.eps_start, precision=prec)
+        sp.finished()
+    held = None                                        # finished games held back until --min-window-games have accumulated
     pending, th = None, None
-    for r in range(a.rounds + (1 if a.pipeline_rounds else 0)):
+    n_win = a.rounds - n_classic
+    for r in range(n_win + (1 if a.pipeline_rounds else 0)):
         L.update_learning_params(games_done // max(1, a.schedule_div))
         if a.lam is not None:
             L.lambda_decay = a.lam
         eps = a.eps if a.eps is not None else a.eps_start + (a.eps_end - a.eps_start) * min(1.0, games_done / total_games)
-        sg = a.scale_games if a.scale_warmup <= 0 else min(a.scale_games, a.scale_warmup * 2.0 ** r)
+        sg = a.scale_games if a.scale_warmup <= 0 else min(a.scale_games, a.scale_warmup * 2.0 ** (r + n_classic))
         scale = min(1.0, sg / (a.slots * world))
         env.load_weights(L.theta.cpu().numpy())        # the weights the last finished replay left
         if a.pipeline_rounds and pending is not None:
             th = threading.Thread(target=replay, args=(pending, scale))
             th.start()
         table = None
-        if r < a.rounds:
+        if r < n_win:
             sp.play(a.window_steps, epsilon=eps, precision=prec)
             table = sp.finished(keep_margin=a.window_steps if a.pipeline_rounds else 0)
             dropped += sp.dropped
@@ -78,6 +86,11 @@ def run_continuous(a, env, arena, L, group, world, prec, say):
             else:                                      # (pipelined: the learner's thread owns the process group while it replays -- two threads
                 n_fin *= world                         #  must not interleave collectives; every rank finishes ~ the same number of games)
             games_done += int(n_fin.item())
+            if held is not None:
+                table = tuple(torch.cat([h, t]) for h, t in zip(held, table))
+                held = None
+            if int(table[0].numel()) < a.min_window_games and r + 1 < n_win:
+                held, table = table, None              # too few games for a replay of their own: they go with the next window's
         if a.pipeline_rounds:
             if th is not None:
                 th.join()
@@ -88,9 +101,11 @@ def run_continuous(a, env, arena, L, group, world, prec, say):
             replay(table, scale)
             side.synchronize()
             turns += res["out"][1]
-        if r % 4 == 3 or r >= a.rounds - 1:
-            say(f"window {r + 1}: {games_done} games finished, td loss {res['out'][0] / max(1, res['out'][1]):.5f}, "
-                f"{world * turns / (time.time() - t0):.0f} turns/s" if res else f"window {r + 1}", flush=True)
+        if a.verbose or r % 4 == 3 or r >= n_win - 1:
+            say(f"window {r + 1}: {games_done} games finished ({int(table[0].numel()) if table is not None else 0} in this window, mean len "
+                f"{float(table[2].float().mean().item()) if table is not None and table[0].numel() else 0.0:.1f}), eps {eps:.3f}, " +
+                (f"td loss {res['out'][0] / max(1, res['out'][1]):.5f} over {res['out'][1]} turns, {world * turns / (time.time() - t0):.0f} turns/s" if res else "no replay yet"),
+                flush=True)
     torch.cuda.synchronize()
     say(f"{games_done} games, {turns} turns replayed per rank in {time.time() - t0:.2f} s; {dropped} games dropped (longer than the ring allows)", flush=True)
     w_after = L.theta.cpu().numpy()
@@ -132,6 +147,16 @@ def main():
                     "replays the games that ended in it (needs --slots).  Games in flight go on under the refreshed weights: a documented deviation")
     ap.add_argument("--window-steps", type=int, default=84, help="env steps per window of --continuous (84 steps of n lanes ~ n finished games)")
     ap.add_argument("--ring-steps", type=int, default=1024, help="depth of the ring log of --continuous (games longer than ring - 2 windows are dropped)")
+    ap.add_argument("--verbose", action="store_true", help="a line per round / window")
+    ap.add_argument("--burn-in-windows", type=int, default=0, help="--continuous: windows played (and not replayed) before the first one that counts: all lanes "
+                    "start at ply 0 together, so the games that END in the first windows are the short ones only; after ~3 windows the lanes are out of "
+                    "step and a window's finished games are an unbiased sample")
+    ap.add_argument("--min-window-games", type=int, default=0, help="--continuous: a window's finished games are held back and replayed together with the next "
+                    "window's until at least this many have accumulated")
+    ap.add_argument("--classic-rounds", type=int, default=0, help="--continuous: this many of --rounds are played first as classic rounds (one game per "
+                    "lane to the end, then the replay: the reference's loop, train.py:527-547), the rest as windows: the first rounds of a run from random "
+                    "weights are the fragile ones (DESIGN §7)")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the self-play env's dice")
     ap.add_argument("--pipeline-rounds", action="store_true", help="with --continuous: the learner replays window w-1 on its own stream (and host "
                     "thread) WHILE the env plays window w -- the self-play policy is one window staler than train.py:519-547's snapshot")
     ap.add_argument("--in-library-collective", action="store_true", help="multi-rank: the per-step all-reduce is issued by the library on the "
@@ -154,9 +179,9 @@ def main():
         dist.init_process_group(a.dist_backend)
         group = dist.group.WORLD
         off, stride = shard_for_rank(rank, world, a.games)
-        env = bg.VecGame(a.games, seed=1, lane_offset=off, lane_stride=stride)
+        env = bg.VecGame(a.games, seed=a.seed, lane_offset=off, lane_stride=stride)
     else:
-        env = bg.VecGame(a.games, seed=1)
+        env = bg.VecGame(a.games, seed=a.seed)
     arena = bg.VecGame(a.arena, seed=2)
     say = print if rank == 0 else (lambda *x, **k: None)
     prec = (bg.BF16 if a.precision == "bf16" else
@@ -168,12 +193,11 @@ def main():
     if a.in_library_collective and not a.host_learner:
         L.init_collective(group)
     say("before: vs random", head_to_head(arena, L.theta.cpu().numpy(), None)["win_rate"], flush=True)
-    if a.continuous:
-        return run_continuous(a, env, arena, L, group, world, prec, say)
     t0, turns = time.time(), 0
     total_games = a.rounds * a.games * world
     first_dice = None
-    for r in range(a.rounds):
+    n_classic = min(a.classic_rounds, a.rounds) if a.continuous else a.rounds
+    for r in range(n_classic):
         games_done = r * a.games * world
         L.update_learning_params(games_done // max(1, a.schedule_div))
         if a.lam is not None:
@@ -194,9 +218,11 @@ def main():
         else:
             sq, cnt = L.replay_rows(rows, lengths, p1_won, group=group, batch_scale=scale, sub_round=a.sub_round, slots=a.slots)
         turns += cnt
-        if r % 20 == 19 or r == a.rounds - 1:
+        if a.verbose or r % 20 == 19 or r == a.rounds - 1:
             say(f"round {r + 1}: {(r + 1) * a.games * world} games, mean len {cnt / a.games:.1f}, td loss {sq / cnt:.5f}, "
                 f"{world * turns / (time.time() - t0):.0f} turns/s", flush=True)
+    if a.continuous:
+        return run_continuous(a, env, arena, L, group, world, prec, say, n_classic, t0, turns)
     w_after = L.theta.cpu().numpy()
     if world > 1:                                             # the replicas must still hold the same weights
         chk = torch.tensor([float(np.abs(w_after).sum()), -float(np.abs(w_after).sum())], dtype=torch.float64, device="cuda")
