@@ -71,6 +71,8 @@ SYMBOLS = [
     ("bgamd_evaluate", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("bgamd_evaluate_slot", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("bgamd_evaluate_incremental", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P]),
+    ("bgamd_build_flags", C.c_char_p, []),
+    ("bgamd_env_kernel_choice", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("bgamd_env_time_kernels", C.c_int, [_P, C.c_int]),
     ("bgamd_env_kernel_times", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("bgamd_pack_rows", C.c_int, [_P, _P, C.c_int64, _P, _P]),

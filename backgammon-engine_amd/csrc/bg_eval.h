@@ -897,12 +897,14 @@ __device__ __forceinline__ void root3_body(const Fetch fetch, long long n_rows, 
     }
 }
 
+#ifdef BGAMD_EXPERIMENTAL       // (BGAMD_ROOT_RESIDENT=0: the env's LDS-staged root pass of rounds 1-2; root_hidden_resident_kernel gives the same bits)
 __global__ __launch_bounds__(ROOT3_THREADS) void root_hidden_bf16x3_kernel(
     const uint4 *__restrict__ rows, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
     const float *__restrict__ b1, float *__restrict__ hidden)
 {
     root3_body<RootRowsFetch, true>(RootRowsFetch{rows}, n_rows, wl3, lut, b1, hidden);
 }
+#endif
 
 // the learner's forward pass: plain W1 x + b1 for s_t and s_{t+1} of every running game (row 2 i + s), bg_learner.h
 __global__ __launch_bounds__(ROOT3_THREADS) void traj_hidden_bf16x3_kernel(
@@ -918,6 +920,7 @@ __global__ __launch_bounds__(ROOT3_THREADS) void traj_hidden_bf16x3_kernel(
 // gives such a step only 16 workgroups and each of them 86 KB of staging; the VALU forward kernel re-reads W1 per workgroup
 // (104 MB per step at 2 048 slots).  The MFMAs run in the staged kernel's order (K-step outer, plane inner): the same bits.
 constexpr int ROOT3D_THREADS = 256;
+#ifdef BGAMD_EXPERIMENTAL       // (BGAMD_TD_FUSED=0: the unfused forward pass; td_forward_mfma_kernel / td_step_fused_kernel carry the same product)
 __global__ __launch_bounds__(ROOT3D_THREADS) void traj_hidden_direct_kernel(
     const uint4 *__restrict__ rows, const int4 *__restrict__ gmeta, long long t, long long n_lanes, long long T, long long n_rows,
     const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut, const float *__restrict__ b1, float *__restrict__ hidden)
@@ -974,6 +977,7 @@ __global__ __launch_bounds__(ROOT3D_THREADS) void traj_hidden_direct_kernel(
         if (orow < n_rows) hidden[orow * N_HID + 32 * c + r] = acc[j] + bb;
     }
 }
+#endif
 
 // position of W1[n][f] in ONE bf16 plane of the root3 layout (relayout_w1_bf16x3), in 16-bit units
 __host__ __device__ __forceinline__ int root3_plane_index(int n, int f)

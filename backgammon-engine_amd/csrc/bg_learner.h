@@ -895,9 +895,13 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_wide_kernel(TdView v
 #ifndef BG_TD_WT
 #define BG_TD_WT 1
 #endif
+// INVARIANT the asm relies on: the compiler does not see this store (no alias analysis, no waitcnt bookkeeping for it), so NOTHING in the
+// launch may read back an address stored through it -- issue() / process() of the trace passes read a trace row strictly before they
+// store it and never again, the partial sums are written once at the end -- and vmcnt retires in order on gfx9, so the counted waits
+// around it stay correct.  The sc1 modifier is gfx94x / gfx950 ISA: any other target takes the plain store.
 __device__ __forceinline__ void td_store_wt(td_f32x4 *p, td_f32x4 x)
 {
-#if BG_TD_WT
+#if BG_TD_WT && (defined(__gfx942__) || defined(__gfx950__))
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
 #else
     *p = x;

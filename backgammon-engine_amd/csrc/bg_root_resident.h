@@ -1,0 +1,106 @@
+// bg_root_resident.h -- the value net's ROOT PASS (one dense W1 x + b1 per game: the root term of the incremental evaluator, bg_eval.h)
+// with the weights resident in registers: the default since round 3 (model.py:63-67's first layer on the position every game is in at
+// the start of its turn, model.py:209).  Split out of bg_eval_dense16.h in round 4, when the kernels that lost their A/B moved behind
+// -DBGAMD_EXPERIMENTAL: this one won its A/B.
+#pragma once
+#include "bg_eval.h"
+
+namespace bg {
+
+constexpr int D16_XBUF_U4 = K16_STEPS * 64;             // uint4 per tile: [13 K-steps][64 lanes]
+
+// ================================ the root pass with the weights resident in registers =====================================
+// root_hidden_bf16x3_kernel (bg_eval.h, rounds 1-2; experimental build only now) stages the three bf16 planes of W1 (160 KB) through LDS in two K phases per workgroup
+// and needs 21 us for 4 us worth of MFMAs.  Same product, same MFMA sequence per accumulator (K-step ascending, planes hi, mid,
+// lo inside a step: the same bits), organised like eval_rows_d16_kernel (bg_eval_dense16.h): a workgroup of four waves, wave c keeps the three
+// planes of ITS 32 hidden units in 156 registers for the whole launch, the 13 A operands of a 32-game tile are decoded once
+// into LDS (a quarter of the K-steps per wave), rows arrive by LDS-DMA two tiles ahead, one block barrier per tile.
+constexpr int ROOTR_THREADS = 256;
+constexpr int ROOTR_LDS_BYTES = 2 * D16_XBUF_U4 * 16 + EVAL16_LUT_BYTES + 3 * 1024;
+
+__global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
+    const uint4 *__restrict__ rows, long long n_rows, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
+    const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    extern __shared__ uint4 sRR[];
+    uint4 *sX = sRR;                                                      // [2][13][64]
+    uint2 *sLut = reinterpret_cast<uint2 *>(sX + 2 * D16_XBUF_U4);
+    uint4 *sRows = reinterpret_cast<uint4 *>(sLut + 16);                  // [3][64]
+    if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
+    const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const long long n_tiles = (n_rows + 31) >> 5;
+    union WF { uint4 u; bf16x8 v; };
+    WF wf[3][K16_STEPS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < K16_STEPS; ++s) wf[p][s].u = wl3[(size_t)p * ROOT3_PART_U4 + ((size_t)s * 4 + c) * 64 + lane];
+    constexpr float NL2E = -1.44269504088896340736f;
+    const float bb = b1[32 * c + r];
+    __syncthreads();
+
+    auto fetch = [&](long long tile, int slot) {
+        if (c == 0 && tile * 32 + (lane >> 1) < n_rows)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rows + tile * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(sRows + slot * 64), 16, 0, 0);
+    };
+    // the A operands wave c decodes for a tile: K-steps c, c + 4, c + 8, and the tail step for wave 0 (exactly root3_body's operands)
+    auto stage = [&](long long tile, int buf, int slot) {
+        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool row_ok = tile < n_tiles && tile * 32 + r < n_rows;
+        if (row_ok) {
+            const uint4 u0 = sRows[slot * 64 + 2 * r], u1 = sRows[slot * 64 + 2 * r + 1];
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+        const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+        uint4 *dst = sX + buf * D16_XBUF_U4 + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pos = 2 * (c + 4 * q) + h + 1;
+            const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+            dst[(c + 4 * q) * 64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+        if (c == 0) {
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
+            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            dst[12 * 64] = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+        }
+    };
+
+    long long tile = blockIdx.x;
+    fetch(tile, 0);
+    fetch(tile + gridDim.x, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(tile, 0, 0);
+    __syncthreads();
+    int it = 0, slot = 0;
+    for (; tile < n_tiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        fetch(tile + 2 * (long long)gridDim.x, slot2);
+        stage(tile + gridDim.x, buf ^ 1, slot1);
+        floatx16 acc = {0};
+        const uint4 *xp = sX + buf * D16_XBUF_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < K16_STEPS; ++s) {
+            WF x;
+            x.u = xp[s * 64];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.v, wf[p][s].v, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long orow = tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (orow < n_rows) hidden[orow * N_HID + 32 * c + r] = NL2E * (acc[j] + bb);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // wave 0: the rows it requested have landed
+        __syncthreads();
+        slot = slot1;
+    }
+}
+
+}  // namespace bg

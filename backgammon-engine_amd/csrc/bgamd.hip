@@ -22,8 +22,16 @@
 #include "../../include/bgamd.h"
 #include "bg_board.h"
 #include "bg_eval.h"
+#include "bg_root_resident.h"
+// Kernels that lost their same-box A/B (DESIGN.md §4 / NOTEBOOK.md) compile only with -DBGAMD_EXPERIMENTAL (the library
+// __graft_entry__.build_experimental() makes; the tests marked gpu_experimental run against it): the K-compacted MFMA delta kernel
+// (BGAMD_MFMA_DELTA=1), the dense f16 x 2 kernel with register-resident weights (BGAMD_F16X2_RESIDENT=1), the LDS-staged / f32-MFMA root
+// passes (BGAMD_ROOT_RESIDENT=0, BGAMD_ROOT_F32=1), the learner's unfused matrix-pipe forward (BGAMD_TD_FUSED=0).  In the default build
+// those switches are ignored and bgamd_build_flags() says so.
+#ifdef BGAMD_EXPERIMENTAL
 #include "bg_eval_mfma.h"
 #include "bg_eval_dense16.h"
+#endif
 #include "bg_learner.h"
 #include "bg_schedule.h"
 #include "bg_movegen.h"
@@ -661,6 +669,7 @@ struct bgamd_env {
     int32_t *d_scalar = nullptr;           // device staging of the scalar (host-argument) surface: args at [0..63], results behind
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
+    int choice[4] = {0, 0, 0, 0};           // kernels of the last greedy step (bgamd_env_kernel_choice)
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     bool root_resident = true;             // the bf16 x 3 root pass with W1 resident in registers (same bits as the LDS-staged kernel, BGAMD_ROOT_RESIDENT=0).
@@ -781,12 +790,17 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         g_hip_err = why;
         return rc;
     }
-    env->root_f32_mfma = getenv("BGAMD_ROOT_F32") != nullptr;
-    env->root_resident = !(getenv("BGAMD_ROOT_RESIDENT") != nullptr && atoi(getenv("BGAMD_ROOT_RESIDENT")) == 0);
+#ifdef BGAMD_EXPERIMENTAL
+    // every BGAMD_* switch reads the same way: set and atoi() != 0 (bench.py mirrors it through bgamd_env_kernel_choice, not the environment)
+    auto on = [](const char *name) { const char *v = getenv(name); return v != nullptr && atoi(v) != 0; };
+    auto off = [](const char *name) { const char *v = getenv(name); return v != nullptr && atoi(v) == 0; };
+    env->root_f32_mfma = on("BGAMD_ROOT_F32");
+    env->root_resident = !off("BGAMD_ROOT_RESIDENT");
     // round 3's K-compacted MFMA delta kernel (bg_eval_mfma.h) is correct and canonical but measured 10 % slower than the VALU
-    // kernel on the same box: opt-in
-    env->mfma_delta = getenv("BGAMD_MFMA_DELTA") != nullptr && atoi(getenv("BGAMD_MFMA_DELTA")) != 0;
-    env->d16 = getenv("BGAMD_F16X2_RESIDENT") != nullptr && atoi(getenv("BGAMD_F16X2_RESIDENT")) != 0;
+    // kernel on the same box (NOTEBOOK.md): opt-in, experimental build only
+    env->mfma_delta = on("BGAMD_MFMA_DELTA");
+    env->d16 = on("BGAMD_F16X2_RESIDENT");
+#endif
     // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
     // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
@@ -829,11 +843,15 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&env->d_w[k], N_PARAMS * 4));
         HIPCHK(hipMalloc(&env->d_wl[k], EVAL_LDS_BYTES));
         HIPCHK(hipMalloc(&env->d_wt[k], DELTA_W_FLOATS * 4));
+#ifdef BGAMD_EXPERIMENTAL
         HIPCHK(hipMalloc(&env->d_wm[k], MD_W_BYTES));
+#endif
         HIPCHK(hipMalloc(&env->d_wl3[k], 3 * EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
+#ifdef BGAMD_EXPERIMENTAL
         HIPCHK(hipMalloc(&env->d_wd16[k], EVAL16X2_W_BYTES));
+#endif
     }
     HIPCHK(hipMalloc(&env->d_lut16, EVAL16_LUT_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL16X2_LDS_TOTAL));
@@ -871,10 +889,14 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
     }
     HIPCHK(hipMemset(v.counters, 0, C_COUNT * 8));
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
+#ifdef BGAMD_EXPERIMENTAL
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
+#endif
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DELTA_LDS_TOTAL));
+#ifdef BGAMD_EXPERIMENTAL
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_mdelta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)root_hidden_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROOT3_LDS_TOTAL));
+#endif
     return BGAMD_OK;
 }
 
@@ -1204,9 +1226,11 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     std::vector<float> wt((size_t)DELTA_W_FLOATS);
     relayout_w1_delta(h_weights, wt.data());
     HIPCHK(hipMemcpy(env->d_wt[slot], wt.data(), DELTA_W_FLOATS * 4, hipMemcpyHostToDevice));
+#ifdef BGAMD_EXPERIMENTAL
     std::vector<uint32_t> wmd((size_t)MD_W_DWORDS);
     env->wm_ok[slot] = relayout_w1_mdelta(h_weights, wmd.data()) >= 0;
     HIPCHK(hipMemcpy(env->d_wm[slot], wmd.data(), MD_W_BYTES, hipMemcpyHostToDevice));
+#endif
     std::vector<uint16_t> wl3((size_t)3 * K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16x3(h_weights, wl3.data());
     HIPCHK(hipMemcpy(env->d_wl3[slot], wl3.data(), 3 * EVAL16_W_BYTES, hipMemcpyHostToDevice));
@@ -1220,8 +1244,10 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     relayout_w1_f16x2(h_weights, wx2.data());
     make_count_lut_f16(lut);
     HIPCHK(hipMemcpy(env->d_wlx2[slot], wx2.data(), EVAL16X2_W_BYTES, hipMemcpyHostToDevice));
+#ifdef BGAMD_EXPERIMENTAL
     relayout_w1_d16(h_weights, wx2.data());
     HIPCHK(hipMemcpy(env->d_wd16[slot], wx2.data(), EVAL16X2_W_BYTES, hipMemcpyHostToDevice));
+#endif
     HIPCHK(hipMemcpy(env->d_lut16, lut, EVAL16_LUT_BYTES, hipMemcpyHostToDevice));
     env->has_weights[slot] = true;
     return BGAMD_OK;
@@ -1240,6 +1266,7 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
     long long eb = (est_rows + (EVAL_THREADS / 64) * 32 - 1) / ((EVAL_THREADS / 64) * 32);
     eb = eb < 1 ? 1 : (eb > env->n_cu ? env->n_cu : eb);
     const dim3 egrid((unsigned)eb);
+#ifdef BGAMD_EXPERIMENTAL
     if (precision == BGAMD_F16X2 && env->d16) {
         KTimer t(env, s, 1);
         long long tiles = (est_rows + 31) / 32;
@@ -1249,7 +1276,9 @@ static int launch_eval(bgamd_env *env, int slot, int precision, const unsigned l
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
                            (const uint4 *)env->d_wd16[slot], (const uint2 *)env->d_lut16, w2, b2, values, info, best,
                            n_rows_ptr ? &env->v.counters[C_KSTEPS] : (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0);
-    } else if (precision == BGAMD_F16X2) {
+    } else
+#endif
+    if (precision == BGAMD_F16X2) {
         KTimer t(env, s, 1);
         hipLaunchKernelGGL(eval_rows_f16x2_kernel, egrid, dim3(EVAL_THREADS), EVAL16X2_LDS_TOTAL, s, rows, n_rows_ptr,
                            n_rows_imm, n_rows_ptr ? &env->v.counters[C_ROWS_EVAL] : (unsigned long long *)nullptr,
@@ -1341,6 +1370,10 @@ struct GreedyRun {
     {
         const long long n = env->v.n;
         hipStream_t s = ss.gen;
+        env->choice[0] = incremental ? ((env->mfma_delta && env->wm_ok[slot]) ? 1 : 0)
+                                     : (precision == BGAMD_F32_DENSE ? 2 : precision == BGAMD_F16X2 ? (env->d16 ? 4 : 3) : 5);
+        env->choice[1] = !incremental ? 0 : (env->root_f32_mfma ? 3 : (env->root_resident ? 1 : 2));
+        env->choice[2] = (incremental && ss.root != s) ? 1 : 0;
         if (incremental) {
             // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
             // It runs on a second stream beside the doubles plies -- small latency-bound launches that leave
@@ -1352,22 +1385,25 @@ struct GreedyRun {
             }
             {
                 KTimer t(env, s2, 6);
+#ifdef BGAMD_EXPERIMENTAL
                 if (env->root_f32_mfma)
                     hipLaunchKernelGGL(eval_rows_f32_kernel<true>, dim3(ss.n_cu), dim3(EVAL_THREADS), EVAL_LDS_TOTAL, s2,
                                        (const uint4 *)sv.root_rows, (const unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
                                        (const float4 *)env->d_wl[slot], b1, w2, b2, sv.root_hidden, (const uint2 *)nullptr,
                                        (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-                else if (env->root_resident) {
-                    long long blocks = (n + 31) / 32;
-                    if (blocks > 2ll * ss.n_cu) blocks = 2ll * ss.n_cu;                 // two 4-wave workgroups per CU (256 VGPRs each wave)
-                    hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS),
-                                       ROOTR_LDS_BYTES, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
-                                       (const uint2 *)env->d_lut, b1, sv.root_hidden);
-                } else {
+                else if (!env->root_resident) {
                     long long blocks = ((n + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
                     if (blocks > ss.n_cu) blocks = ss.n_cu;
                     hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS),
                                        ROOT3_LDS_TOTAL, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
+                                       (const uint2 *)env->d_lut, b1, sv.root_hidden);
+                } else
+#endif
+                {
+                    long long blocks = (n + 31) / 32;
+                    if (blocks > 2ll * ss.n_cu) blocks = 2ll * ss.n_cu;                 // two 4-wave workgroups per CU (256 VGPRs each wave)
+                    hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS),
+                                       ROOTR_LDS_BYTES, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
                                        (const uint2 *)env->d_lut, b1, sv.root_hidden);
                 }
             }
@@ -1391,6 +1427,7 @@ struct GreedyRun {
             // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
             long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
             dblocks = dblocks < 1 ? 1 : (dblocks > ss.n_cu ? ss.n_cu : dblocks);
+#ifdef BGAMD_EXPERIMENTAL
             if (env->mfma_delta && env->wm_ok[slot])
                 hipLaunchKernelGGL(eval_rows_mdelta_kernel, dim3((unsigned)dblocks), dim3(MD_THREADS), MD_LDS_TOTAL, se,
                                    (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
@@ -1399,6 +1436,7 @@ struct GreedyRun {
                                    fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT, &env->v.counters[C_ERR],
                                    (unsigned long long)ERRF_DELTA);
             else
+#endif
             hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, se,
                                (const uint4 *)sv.u_rows, (const unsigned long long *)&sv.tops[T_U], (long long)sv.cap_rows, &env->v.counters[C_ROWS_EVAL],
                                (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
@@ -1634,22 +1672,26 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
     hipLaunchKernelGGL(pack_child_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_root_index, (long long)n,
                        (long long)n_roots, (const uint4 *)sv.root_rows, sv.u_rows, sv.u_info, &env->v.counters[C_ERR]);
     HIPCHK(hipMemsetAsync(sv.best, 0, (size_t)n_roots * 8, s));
-    if (env->root_resident) {
-        long long blocks = (n_roots + 31) / 32;
-        if (blocks > 2ll * env->n_cu) blocks = 2ll * env->n_cu;
-        hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS), ROOTR_LDS_BYTES, s,
-                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
-                           sv.root_hidden);
-    } else {
+#ifdef BGAMD_EXPERIMENTAL
+    if (!env->root_resident) {
         long long blocks = ((n_roots + 31) / 32 + ROOT3_THREADS / 64 - 1) / (ROOT3_THREADS / 64);
         if (blocks > env->n_cu) blocks = env->n_cu;
         hipLaunchKernelGGL(root_hidden_bf16x3_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOT3_THREADS), ROOT3_LDS_TOTAL, s,
+                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
+                           sv.root_hidden);
+    } else
+#endif
+    {
+        long long blocks = (n_roots + 31) / 32;
+        if (blocks > 2ll * env->n_cu) blocks = 2ll * env->n_cu;
+        hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS), ROOTR_LDS_BYTES, s,
                            (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
                            sv.root_hidden);
     }
     long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;
     dblocks = dblocks < 1 ? 1 : (dblocks > env->n_cu ? env->n_cu : dblocks);
     KTimer t(env, s, 1);
+#ifdef BGAMD_EXPERIMENTAL
     if (env->mfma_delta && env->wm_ok[slot])
         hipLaunchKernelGGL(eval_rows_mdelta_kernel, dim3((unsigned)dblocks), dim3(MD_THREADS), MD_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
                            (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const uint4 *)env->d_wm[slot],
@@ -1657,6 +1699,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
                            (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0, &env->v.counters[C_ERR],
                            (unsigned long long)ERRF_DELTA);
     else
+#endif
     hipLaunchKernelGGL(eval_rows_delta_kernel, dim3((unsigned)dblocks), dim3(DELTA_THREADS), DELTA_LDS_TOTAL, s, (const uint4 *)sv.u_rows,
                        (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const float4 *)env->d_wt[slot],
                        w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden, d_values, (const uint2 *)sv.u_info, sv.best,
@@ -1681,6 +1724,27 @@ int bgamd_env_time_kernels(bgamd_env *env, int enable)
             env->ev.push_back(x);
             if (env->ev.size() % 2 == 0) env->ev_kind.push_back(0);
         }
+    return BGAMD_OK;
+}
+
+const char *bgamd_build_flags(void)
+{
+#ifdef BGAMD_EXPERIMENTAL
+    return "experimental";
+#else
+    return "default";
+#endif
+}
+
+int bgamd_env_kernel_choice(bgamd_env *env, int32_t h_out[4])
+{
+    if (!env || !h_out) return BGAMD_E_INVALID;
+    for (int i = 0; i < 3; ++i) h_out[i] = env->choice[i];
+#ifdef BGAMD_EXPERIMENTAL
+    h_out[3] = 1;
+#else
+    h_out[3] = 0;
+#endif
     return BGAMD_OK;
 }
 
@@ -1828,7 +1892,9 @@ int bgamd_td_create(bgamd_td **out, int64_t max_games, int device)
         td->fuse_g = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? g : 0;
     }
     td->no_wide_even = getenv("BGAMD_TD_NO_WIDE_EVEN") != nullptr && atoi(getenv("BGAMD_TD_NO_WIDE_EVEN")) != 0;
-    td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);
+#ifdef BGAMD_EXPERIMENTAL
+    td->fused = !(getenv("BGAMD_TD_FUSED") && atoi(getenv("BGAMD_TD_FUSED")) == 0);      // (the unfused matrix-pipe forward: experimental build only)
+#endif
     if (getenv("BGAMD_TD_DIRECT_MIN")) td->direct_min = atoll(getenv("BGAMD_TD_DIRECT_MIN"));
     td->lazy = !(getenv("BGAMD_TD_LAZY") && atoi(getenv("BGAMD_TD_LAZY")) == 0);
     HIPCHK(hipMemset(v.act_cols, 0, (size_t)max_games * 4));
@@ -1975,7 +2041,9 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     const long long fuse_groups_max = td->n_cu < TD_MAX_GROUPS ? td->n_cu : TD_MAX_GROUPS;
     int fuse_g = td->fuse_g > 0 ? td->fuse_g : 1;
     if (td->fuse_g <= 0) while (fuse_g < 16 && (n_active + fuse_g - 1) / fuse_g > fuse_groups_max) fuse_g *= 2;
-    const bool fused_step = td->fuse_step && td->pipe && !td->no_wide_even && n_active >= td->fuse_min && n_active < td->mfma_min &&
+    // (BGAMD_TD_FUSED=0 / BGAMD_TD_DIRECT_MIN choose the forward kernel: a step that is to run the unfused or the VALU forward pass cannot take the
+    //  launch that contains the fused one)
+    const bool fused_step = td->fuse_step && td->pipe && td->fused && n_active >= td->direct_min && !td->no_wide_even && n_active >= td->fuse_min && n_active < td->mfma_min &&
                             n_active < td->nt_min && (n_active + fuse_g - 1) / fuse_g <= fuse_groups_max;
     if (fused_step) {
     } else if (n_active >= td->mfma_min) {
@@ -1991,6 +2059,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
     } else if (n_active >= td->direct_min && td->fused) {
         // mid-sized steps: the product and its epilogue in one launch (bg_learner.h)
         hipLaunchKernelGGL(td_forward_mfma_kernel, grid1(n_active, TD_FUSED_GAMES), dim3(ROOT3D_THREADS), 0, s, v, (long long)t, (long long)n_active, alpha);
+#ifdef BGAMD_EXPERIMENTAL
     } else if (n_active >= td->direct_min) {
         // mid-sized steps: the same product, a workgroup per 32-row tile and the weight planes straight from the L2 (bg_eval.h)
         const long long n_rows = 2 * n_active;
@@ -1998,6 +2067,7 @@ int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float
                            (const int4 *)v.gmeta, (long long)t, v.n_lanes, v.T, n_rows, (const uint4 *)v.wl3, (const uint2 *)v.lut,
                            (const float *)(v.theta + TD_OFF_B1), v.hid);
         hipLaunchKernelGGL(td_epilogue_wave_kernel, grid1(n_active, 4), dim3(256), 0, s, v, (long long)t, (long long)n_active, alpha);
+#endif
     } else if (n_active <= 8192)
         hipLaunchKernelGGL((td_forward_kernel<2, false>), grid1(n_active, 2), dim3(128), 0, s, v, (long long)t, (long long)n_active, alpha);
     else

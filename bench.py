@@ -169,6 +169,46 @@ def training_round(bg, games, w):
             (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, batch_scale=24.0 / (kw.get("slots") or games), **kw))
         out[name] = {"replay_ms": round(1e3 * dt, 2), "td_updates_per_s": round(cnt / dt, 1),
                      "round_turns_per_s": round(turns / (dt + dt_play), 1)}
+    # round 4: continuous self-play (every lane restarts the step after its game ended; ring log by env step) in windows of 84 steps of all
+    # lanes -- about as many turns as a round -- with the replay of the games that ended in the window after it, and BESIDE the next window
+    # (learner on its own stream and host thread; tools/train_pipeline.py is the stand-alone A/B, DESIGN.md §7 the numbers)
+    import threading
+    from backgammon_env.learner import ContinuousSelfPlay
+    L = DeviceTDLambdaLearner(w, max_games=2048, alpha=0.1, lam=0.7)
+    side = torch.cuda.Stream()
+    dev_i = torch.cuda.current_device()
+    for pipe in (False, True):
+        sp = ContinuousSelfPlay(env, ring_steps=1024)
+        res, times, t_play = {}, [], []
+
+        def replay(tab):
+            torch.cuda.set_device(dev_i)
+            with torch.cuda.stream(side):
+                res["r"] = L.replay_games(sp.rows, *tab, slots=2048, batch_scale=24.0 / 2048)
+            side.synchronize()
+        pending = None
+        for r in range(8):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            th = None
+            if pipe and pending is not None:
+                th = threading.Thread(target=replay, args=(pending,)); th.start()
+            sp.play(84, epsilon=0.05)
+            tab = sp.finished(keep_margin=84 if pipe else 0)
+            t_play.append(time.perf_counter() - t0)
+            if pipe:
+                if th is not None:
+                    th.join()
+                pending = tab
+            else:
+                replay(tab)
+            torch.cuda.synchronize()
+            if r >= 4:
+                times.append(time.perf_counter() - t0)
+        ms, trn = 1e3 * float(np.median(times)), res["r"][1]
+        out["continuous_window_84_steps" + ("_replay_beside_the_next_window" if pipe else "")] = {
+            "window_ms": round(ms, 2), "selfplay_ms": round(1e3 * float(np.median(t_play[4:])), 2) if not pipe else None,
+            "turns_replayed": trn, "round_turns_per_s": round(trn / ms * 1e3, 1)}
+        sp.close()
     del L, env
     return out
 
@@ -278,6 +318,7 @@ def main():
 
     kt = env.kernel_times() if not a.no_kernel_timing else None
     env.time_kernels(False)
+    choice = env.kernel_choice()                 # what the timed region's steps launched (asked of the library, not read from the environment)
     st = env.stats()
     # the counters cover every region; all regions do the same amount of work (auto-reset keeps every lane live), so
     # the median region's share is 1 / len(regions) of each
@@ -333,7 +374,7 @@ def main():
         # the timed region, as measured: every region is EXACTLY `steps` steps; more than one when the first was < 10 ms
         "timed_regions": len(regions), "region_ms": {"min": round(1e3 * min(regions), 4), "median": round(1e3 * elapsed, 4),
                                                      "max": round(1e3 * max(regions), 4)},
-        "source_hash": bg._capi.source_hash(),
+        "source_hash": bg._capi.source_hash(), "library_build": bg._capi.load().bgamd_build_flags().decode(),
     }
     if kt:
         nl = a.steps                                  # launches of the value-net kernel in the timed region (one per step)
@@ -366,18 +407,18 @@ def main():
             stage_ms = per["eval"] + per.get("root", 0.0)
             lds_tbps = ks_l * 512 / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
             occ = {}
-            for occ_file in ("r03_valu_occupancy.json", "r02_valu_occupancy.json"):
+            for occ_file in ("r04_valu_occupancy.json", "r03_valu_occupancy.json", "r02_valu_occupancy.json"):
                 try:                                      # VALU issue occupancy from the COMMITTED SQ counters (tools/valu_occupancy.py): a number
                     occ = json.load(open(os.path.join(ROOT, "profiles", occ_file)))     # of another run of this kernel, not of this one
                     occ["source"] = "profiles/%s: %s" % (occ_file, occ.get("source", ""))
                     break
                 except Exception:
                     continue
-            mdelta = os.environ.get("BGAMD_MFMA_DELTA") == "1"        # round 3's opt-in kernel for the same stage
+            mdelta = choice["eval"] == "eval_rows_mdelta_kernel"      # round 3's kernel for the same stage (experimental build + BGAMD_MFMA_DELTA=1)
             ev = {"bound": "valu", "achieved": round(exec_tf, 3), "peak": PEAK_VALU_F32, "unit": "TFLOP/s",
                   "frac": round(exec_tf / PEAK_VALU_F32, 4), "traffic": None, "avg_ms": round(per["eval"], 4),
                   "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
-                  "kernel": "eval_rows_mdelta_kernel" if mdelta else "eval_rows_delta_kernel", "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
+                  "kernel": choice["eval"], "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
                   "flop_per_launch": int(ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE),
                   "dense_equiv_tflops": round(eval_tf, 2), "dense_equiv_vs_f32_mfma_peak": round(eval_tf / peak, 3),
                   # second resource: one 512-byte W1 column per (row, changed feature) out of LDS, ds_read_b128
@@ -385,7 +426,7 @@ def main():
                   "lds_peak_TBps": PEAK_LDS_TBPS, "lds_frac": round(lds_tbps / PEAK_LDS_TBPS, 4),
                   "valu_issue_occupancy": None if mdelta else occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
                   "valu_issue_occupancy_source": None if mdelta else occ.get("source"),
-                  "root_pass_kernel": "root_hidden_bf16x3_kernel" if os.environ.get("BGAMD_ROOT_RESIDENT") == "0" else "root_hidden_resident_kernel",
+                  "root_pass_kernel": choice["root"], "root_pass_on_second_stream": choice["root_on_second_stream"],
                   "root_pass_avg_ms": round(per.get("root", 0.0), 4), "root_pass_tflops": round(root_tf, 2),
                   "root_pass_frac_of_f32_mfma_peak": round(root_tf / peak, 4),
                   "value_net_stage_ms": round(stage_ms, 4),
@@ -397,7 +438,7 @@ def main():
                           "(valu_issue_occupancy, tools/valu_occupancy.py over profiles/) is far above frac."}
         else:
             exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
-            ev.update({"kernel": "eval_rows_%s_kernel" % ("f32" if a.precision == "f32_dense" else a.precision),
+            ev.update({"kernel": choice["eval"],
                        "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
                        "executed_frac_of_peak": round(exec_tf / peak, 4) if exec_tf else None,
                        "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
@@ -413,7 +454,7 @@ def main():
         }
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs; bench.py cannot
         # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
-        for pmc_file in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
                 for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_kernel<3>")):

@@ -250,6 +250,14 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * beside the doubles plies; for envs of 28 672 lanes and more -- smaller ones keep it on the caller's stream, where it is faster; BGAMD_NO_OVERLAP=1 / BGAMD_OVERLAP=1 in the environment force either).  enable: 0 = off, 1 = every group, (mask << 8) | (stride << 20) = only the groups
  * whose bit is set in mask, on every stride-th launch of a group (0 = every launch; an event pair costs ~4 us of
  * stream time, so a timed run samples). */
+/* "default" or "experimental" (-DBGAMD_EXPERIMENTAL: the kernels that lost their A/B are compiled in and their switches honoured --
+ * BGAMD_MFMA_DELTA, BGAMD_F16X2_RESIDENT, BGAMD_ROOT_RESIDENT=0, BGAMD_ROOT_F32, BGAMD_TD_FUSED=0; the default build ignores them).
+ * bgamd_env_kernel_choice: what the last greedy step actually launched -- h_out[0] value net: 0 eval_rows_delta_kernel, 1 eval_rows_mdelta_kernel,
+ * 2 eval_rows_f32_kernel, 3 eval_rows_f16x2_kernel, 4 eval_rows_d16_kernel, 5 eval_rows_bf16_kernel; h_out[1] root pass: 0 none, 1
+ * root_hidden_resident_kernel, 2 root_hidden_bf16x3_kernel, 3 eval_rows_f32_kernel<root>; h_out[2]: 1 = root pass on the env's second
+ * stream; h_out[3]: 1 = experimental build.  bench.py labels its kernels from this, not from the environment. */
+const char *bgamd_build_flags(void);
+int bgamd_env_kernel_choice(bgamd_env *env, int32_t h_out[4]);
 int bgamd_env_time_kernels(bgamd_env *env, int enable);
 int bgamd_env_kernel_times(bgamd_env *env, double h_ms[8], uint64_t h_launches[8]);
 
@@ -335,7 +343,9 @@ int bgamd_td_written_columns(bgamd_td *td, uint64_t *h_columns);
 /* Diagnostics: the replay's slots (lock-step: one per game) -> int32 h_out[n][6] = (lane, length, p1_won, start step) of the game
  * a slot holds (length 0: none), the slot's queue cursor (-1 in a lock-step replay), its (game, step) updates so far.  Synchronises. */
 int bgamd_td_slots(bgamd_td *td, int32_t *h_out);
-/* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1) */
+/* HIP-event time of the trace kernel since the last call: enable with bgamd_td_time(td, 1).  A step of 512 .. 4 096 slots runs its forward pass
+ * INSIDE the trace launch (td_step_fused_kernel): the bracket then holds both, and bytes / time derived from it understate the trace pass
+ * (BGAMD_TD_FUSE_STEP=0 at bgamd_td_create separates them again: forward kernel, trace kernel, reduce kernel). */
 int bgamd_td_time(bgamd_td *td, int enable);
 int bgamd_td_times(bgamd_td *td, double *h_trace_ms, uint64_t *h_launches, uint64_t *h_game_steps);
 

@@ -12,8 +12,24 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _wants_experimental(config):
+    return "gpu_experimental" in (config.getoption("-m") or "")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_experimental: needs a real MI355X AND the -DBGAMD_EXPERIMENTAL build of the library (the kernels that "
+                            "lost their A/B); run with -m gpu_experimental -- tools/round_check.sh does -- not part of -m gpu")
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu_experimental tests run only when asked for by name: `-m "not gpu"` (the CPU suite) must not pick them up."""
+    if _wants_experimental(config):
+        return
+    skip = pytest.mark.skip(reason="experimental-build test: run with -m gpu_experimental")
+    for it in items:
+        if it.get_closest_marker("gpu_experimental"):
+            it.add_marker(skip)
 
 
 def pytest_sessionstart(session):
@@ -21,6 +37,8 @@ def pytest_sessionstart(session):
     from) and a no-op when fresh, so the tests can never run a libbgamd.so that was not built from the tree they sit
     in (*.so is git-ignored but travels with gpurun snapshots).  hipcc cross-compiles gfx950 without a GPU."""
     import __graft_entry__
+    if _wants_experimental(session.config):          # before anything imports the package (build() does): it binds BGAMD_LIB when it loads
+        os.environ["BGAMD_LIB"] = __graft_entry__.build_experimental()
     __graft_entry__.build()
 
 

@@ -44,9 +44,9 @@ def main():
     r0 = {}
     for rnd in range(3):                                 # three rounds: each plays with the weights the one before left
         rows, lengths, p1_won = play_round(tenv, max_plies=400, epsilon=0.05)
-        # round 0: the whole shard lock-step; round 1: sub-rounds of 256 games per rank (every rank runs the same number);
-        # round 2: streamed through 128 slots per rank (the ranks' step counts differ: the shorter one joins every collective)
-        sub, slots = (0, 0) if rnd == 0 else (256, 0) if rnd == 1 else (0, 128)
+        # round 0: the whole shard lock-step; round 1: two sub-rounds per rank (every rank runs the same number);
+        # round 2: streamed through train_lanes / 4 slots per rank (the ranks' step counts differ: the shorter one joins every collective)
+        sub, slots = (0, 0) if rnd == 0 else (train_lanes // 2, 0) if rnd == 1 else (0, train_lanes // 4)
         a, b = L.replay_rows(rows, lengths, p1_won, group=dist.group.WORLD, sub_round=sub, slots=slots,
                              batch_scale=24.0 / (world * (sub or slots or train_lanes)))
         sq, cnt = sq + a, cnt + b

@@ -425,7 +425,7 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
     """Two FRESH processes (spawned before they touch the GPU) share the one GPU and a gloo group:
       * 2 x 32 768 lanes play, lane for lane, the games of ONE 65 536-lane env (50 greedy steps);
       * the split / all-reduce / apply learner over two shards leaves bit-identical weight replicas that moved."""
-    lanes, steps, train_lanes = 32768, 50, 1024
+    lanes, steps, train_lanes = 32768, 50, 512
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -456,7 +456,7 @@ def test_two_rank_rehearsal_on_one_gpu(bg, weights, tmp_path):
     assert not np.array_equal(r[0]["lengths"], r[1]["lengths"])   # the two shards played different games
     assert r[0]["learner"][1] > 0 and r[1]["learner"][1] > 0
     # sharded == unsharded for the DEVICE learner on the lock-step route: both shards' round-0 logs replayed by ONE learner
-    # (2 048 games, the same per-game step) give the weights the two all-reducing replicas ended round 0 with, to fp32
+    # (1 024 games, the same per-game step) give the weights the two all-reducing replicas ended round 0 with, to fp32
     # rounding -- the sum over the games is associated differently, nothing else
     from backgammon_env.learner import DeviceTDLambdaLearner
     assert np.array_equal(r[0]["r0_theta"], r[1]["r0_theta"])
@@ -559,8 +559,16 @@ def test_scalar_surface_full_games_vs_g3(bg, golden_dir, surface="python_package
     print("Game.clone(): %.2f ms each while the pool fills, %.3f ms from the pool" % (1e3 * dt_first / 50, 1e3 * dt_pool))
 
 
-@pytest.mark.parametrize("variant", ["default", "direct", "direct_unfused", "matrix_pipe", "direct_and_wide", "matrix_pipe_and_wide"])
+@pytest.mark.parametrize("variant", ["default", "direct", "matrix_pipe", "direct_and_wide", "matrix_pipe_and_wide"])
 def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
+    """(variant direct_unfused -- BGAMD_TD_FUSED=0, experimental build -- runs in tests/test_gpu_experimental.py)"""
+    _streamed_replay_variant(bg, weights, variant)
+
+
+_STREAM_CLOSED_FORM = {}
+
+
+def _streamed_replay_variant(bg, weights, variant):
     """bgamd_td_begin_stream: k slots replay the round's games one after another.  Against the float64 host closed form of the
     same schedule (ragged lengths, lanes that are not replayed, a one-turn game), for 1, 7 and 64 slots, on the small-round
     kernels and on the large-round ones (the two matrix-pipe forward kernels, the whole-row trace workgroups: forced down to this size); a slot
@@ -589,8 +597,14 @@ def test_streamed_replay_matches_host_closed_form(bg, weights, variant):
     finally:
         os.environ.pop("BGAMD_TD_MFMA_MIN", None); os.environ.pop("BGAMD_TD_WIDE_MIN", None); os.environ.pop("BGAMD_TD_DIRECT_MIN", None); os.environ.pop("BGAMD_TD_FUSED", None)
     for slots in (1, 7, 64):
-        Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.8, dtype=torch.float64)
-        sq_c, cnt_c = Lc.replay_stream(Xr, lengths.cpu(), p1_won.cpu(), slots=slots, batch_scale=0.3)
+        # the float64 host closed form depends on the round and the slot count only, not on the kernel variant: computed once per session
+        # (the digest of the log is part of the key: another round would be another entry)
+        key = (slots, hash(_np(rows).tobytes()), hash(_np(lengths).tobytes()))
+        if key not in _STREAM_CLOSED_FORM:
+            Lc = TDLambdaLearner(weights, device="cpu", alpha=0.1, lam=0.8, dtype=torch.float64)
+            sq_c, cnt_c = Lc.replay_stream(Xr, lengths.cpu(), p1_won.cpu(), slots=slots, batch_scale=0.3)
+            _STREAM_CLOSED_FORM[key] = (Lc, sq_c, cnt_c)
+        Lc, sq_c, cnt_c = _STREAM_CLOSED_FORM[key]
         out = []
         for Ld in learners[:2]:
             Ld.set_weights(weights)
