@@ -103,4 +103,116 @@ __global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
     }
 }
 
+
+// ---- the same pass INSIDE the step's boundary launch (round 4) ----------------------------------------------------------------------
+// As a launch of its own the root pass costs the step ~25 us at 65 536 lanes (same-box ablation, profiles/r04_ab_root_pass_in_boundary.txt:
+// 0.1441 -> 0.1186 ms per step without it): ~9 us of work, the rest a kernel boundary on the critical path (or, forked onto a second stream,
+// two events and the CUs it takes from the doubles plies and the leaf stage), and the value net reading 33 MB that were written just before.
+// The workgroup of the boundary launch that applies step t and builds the roots of step t + 1 for its 256 games has those 256 root rows in
+// hand: it goes on with THEIR root pass -- 8 tiles of 32 games, wave c = hidden units 32 c .. 32 c + 31, the same operands, the same MFMA
+// sequence per accumulator (K-step ascending; planes hi, mid, lo inside a step) and the same epilogue as root_hidden_resident_kernel:
+// the same bits.  Rows come from LDS (the roots half of the launch puts them there), no launch, no event, no round trip.
+constexpr int BROOT_THREADS = 256;                           // = LANE_NT of the boundary launch: four waves, 8 tiles of 32 games
+constexpr int BROOT_TILES = BROOT_THREADS / 32;
+// all 8 tiles' A operands are staged at once (one block barrier, then 8 x 39 MFMAs per wave back to back): a first version that staged
+// tile by tile behind a barrier each -- root_hidden_resident_kernel's loop -- cost the launch 16.7 us (a chain of 8 x (LDS round trip,
+// 39 dependent MFMAs, stores, barrier) on one wave per SIMD) where the MFMAs are 4.8
+constexpr int BROOT_LDS_BYTES = BROOT_TILES * D16_XBUF_U4 * 16 + EVAL16_LUT_BYTES + BROOT_THREADS * 32;
+
+struct BRootWeights { uint4 w[3][K16_STEPS]; };              // wave c's three bf16 planes of hidden units 32 c .. 32 c + 31: 156 registers
+
+// requested BEFORE the roots half of the launch (they do not depend on it): in flight while the roots scan and allocate
+__device__ __forceinline__ void broot_load_weights(const uint4 *__restrict__ wl3, BRootWeights &wf)
+{
+    const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+#if defined(BG_ABL_STEP) && (BG_ABL_STEP & 8)
+        for (int s = 0; s < K16_STEPS; ++s) wf.w[p][s] = make_uint4(lane + s, p, c, 0u);
+#else
+        for (int s = 0; s < K16_STEPS; ++s) wf.w[p][s] = wl3[(size_t)p * ROOT3_PART_U4 + ((size_t)s * 4 + c) * 64 + lane];
+#endif
+}
+
+// every thread of the workgroup calls it with ITS game's root row (32 bytes; zero for a lane past the env); g0 = the workgroup's first game
+__device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4 row0, uint4 row1, long long g0, long long n_games,
+                                                   const uint2 *__restrict__ lut, const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    extern __shared__ uint4 sBR[];
+    uint4 *sX = sBR;                                                      // [8 tiles][13][64]
+    uint2 *sLut = reinterpret_cast<uint2 *>(sX + BROOT_TILES * D16_XBUF_U4);
+    uint4 *sRows = reinterpret_cast<uint4 *>(sLut + 16);                  // [256][2]
+    if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
+    sRows[2 * threadIdx.x] = row0;
+    sRows[2 * threadIdx.x + 1] = row1;
+    const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    constexpr float NL2E = -1.44269504088896340736f;
+    const float bb = b1[32 * c + r];
+    long long left = n_games - g0;
+    const int n_tiles = left <= 0 ? 0 : (int)((left < BROOT_THREADS ? left : BROOT_THREADS) + 31) >> 5;     // workgroup-uniform
+    __syncthreads();
+    // the A operands wave c decodes for a tile: K-steps c, c + 4, c + 8, and the tail step for wave 0 (exactly root_hidden_resident_kernel's)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool row_ok = g0 + tile * 32 + r < n_games;
+        if (row_ok) {
+            const uint4 u0 = sRows[2 * (tile * 32 + r)], u1 = sRows[2 * (tile * 32 + r) + 1];
+            p[0] = u0.x; p[1] = u0.y; p[2] = u0.z; p[3] = u0.w; p[4] = u1.x; p[5] = u1.y; p[6] = u1.z; p[7] = u1.w;
+        }
+        const Side sa{{p[0], p[1], p[2], p[3]}}, sb{{p[4], p[5], p[6], p[7]}};
+        uint4 *dst = sX + tile * D16_XBUF_U4 + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pos = 2 * (c + 4 * q) + h + 1;
+            const uint2 l0 = sLut[count_at(sa, pos)], l1 = sLut[count_at(sb, pos)];
+            dst[(c + 4 * q) * 64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+        if (c == 0) {
+            const int turn = (p[0] & TURN_BIT) ? 1 : 0;
+            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
+            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            dst[12 * 64] = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
+        }
+    }
+    __syncthreads();
+    union WF { uint4 u; bf16x8 v; };
+    // two tiles per iteration: two independent accumulator chains and twice the LDS reads in flight -- with ONE wave per SIMD nothing else
+    // covers an MFMA chain's and an LDS read's latency (a tile at a time: 2.1 us per tile and wave against 1.25 in the stand-alone kernel,
+    // whose two workgroups per CU cover each other).  Per accumulator the sequence is unchanged: K-step ascending, planes hi, mid, lo.
+#if defined(BG_ABL_STEP) && (BG_ABL_STEP & 2)
+    if (n_tiles > 100)
+#endif
+    for (int tile = 0; tile < n_tiles; tile += 2) {
+        floatx16 acc0 = {0}, acc1 = {0};
+        const uint4 *xp0 = sX + tile * D16_XBUF_U4 + lane;
+        const uint4 *xp1 = sX + (tile + 1 < n_tiles ? tile + 1 : tile) * D16_XBUF_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < K16_STEPS; ++s) {
+            WF x0, x1;
+            x0.u = xp0[s * 64];
+            x1.u = xp1[s * 64];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                WF wv;
+                wv.u = wf.w[p][s];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0.v, wv.v, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1.v, wv.v, acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long orow = g0 + tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+#if defined(BG_ABL_STEP) && (BG_ABL_STEP & 4)
+            if (acc0[j] == 1.2345f || acc1[j] == 1.2345f) hidden[orow * N_HID + 32 * c + r] = 0.0f;
+#else
+            if (orow < n_games) hidden[orow * N_HID + 32 * c + r] = NL2E * (acc0[j] + bb);
+            if (tile + 1 < n_tiles && orow + 32 < n_games) hidden[(orow + 32) * N_HID + 32 * c + r] = NL2E * (acc1[j] + bb);
+#endif
+        }
+    }
+}
+
 }  // namespace bg

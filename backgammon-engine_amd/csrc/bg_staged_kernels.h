@@ -51,7 +51,9 @@ __device__ __forceinline__ void flag_overflow(const EnvView &e)
 constexpr int LANE_NT = BG_LANE_NT;
 
 // pre (optional): the lane's state handed over in registers by the apply of the turn before (boundary_kernel)
-__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr)
+// row_out (optional, [2]): the lane's root row as written to sv.root_rows (zero for a lane past the env), for a caller that goes on with it
+__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr,
+                                           uint4 *row_out = nullptr)
 {
     __shared__ uint32_t s_wave[LANE_NT / 64];
     __shared__ unsigned long long s_slot[2];
@@ -106,10 +108,13 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
             e.traj[t + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
         }
     }
+    if (row_out) { row_out[0] = make_uint4(0u, 0u, 0u, 0u); row_out[1] = make_uint4(0u, 0u, 0u, 0u); }
     if (g < e.n) {
         sv.best[g] = 0ull;
-        sv.root_rows[2 * g] = make_uint4(c.p[0] | (c.turn ? TURN_BIT : 0u), c.p[1], c.p[2], c.p[3]);
-        sv.root_rows[2 * g + 1] = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
+        const uint4 r0 = make_uint4(c.p[0] | (c.turn ? TURN_BIT : 0u), c.p[1], c.p[2], c.p[3]), r1 = make_uint4(c.p[4], c.p[5], c.p[6], c.p[7]);
+        sv.root_rows[2 * g] = r0;
+        sv.root_rows[2 * g + 1] = r1;
+        if (row_out) { row_out[0] = r0; row_out[1] = r1; }
     }
 }
 
@@ -465,12 +470,21 @@ __global__ __launch_bounds__(LANE_NT) void apply_kernel(EnvView e, StagedView sv
 // Step boundary of a multi-step run: the apply of step t and the roots of step t+1 for the same lane in one launch
 // (the lane's new position is read back by the thread that just stored it).  sv_next carries the other set of list
 // counters: the value-net kernel of step t cleared it while nothing was using it.
+// ROOT: the workgroup goes on with the value net's root pass of step t + 1 for its 256 games (bg_root_resident.h: the same bits as
+// root_hidden_resident_kernel; needs LANE_NT == 256 and BROOT_LDS_BYTES of dynamic LDS) -- the step then has no root-pass launch
+template <bool ROOT>
 __global__ __launch_bounds__(LANE_NT) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
-                                                           float epsilon)
+                                                           float epsilon, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
+                                                           const float *__restrict__ b1)
 {
+    static_assert(!ROOT || LANE_NT == BROOT_THREADS, "the in-launch root pass is written for 256-thread workgroups");
     const long long g = (long long)blockIdx.x * LANE_NT + threadIdx.x;
     LaneCtx next;                                       // the lane's new state goes on in registers: no read-back
     apply_body(e, sv, xv, flags, epsilon, g, &next);
     __syncthreads();                                    // finish_turn's statistics scratch is free again
-    roots_body(e, sv_next, flags, g, &next);
+    uint4 row[2];
+    BRootWeights wf;
+    if (ROOT) broot_load_weights(wl3, wf);
+    roots_body(e, sv_next, flags, g, &next, ROOT ? row : nullptr);
+    if (ROOT) boundary_root_pass(wf, row[0], row[1], (long long)blockIdx.x * LANE_NT, e.n, lut, b1, sv_next.root_hidden);
 }

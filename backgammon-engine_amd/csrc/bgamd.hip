@@ -670,6 +670,8 @@ struct bgamd_env {
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
     int choice[4] = {0, 0, 0, 0};           // kernels of the last greedy step (bgamd_env_kernel_choice)
+    bool root_in_boundary = true;          // inside a run the root pass of step t + 1 runs in the boundary launch of step t (bg_root_resident.h);
+                                           //   BGAMD_ROOT_IN_BOUNDARY=0: a launch of its own every step, as up to round 3
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
     bool root_f32_mfma = false;            // root term by the f32 MFMA chain instead of the bf16 x 3 split (BGAMD_ROOT_F32=1)
     bool root_resident = true;             // the bf16 x 3 root pass with W1 resident in registers (same bits as the LDS-staged kernel, BGAMD_ROOT_RESIDENT=0).
@@ -803,6 +805,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
 #endif
     // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
     // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
+    env->root_in_boundary = !(getenv("BGAMD_ROOT_IN_BOUNDARY") != nullptr && atoi(getenv("BGAMD_ROOT_IN_BOUNDARY")) == 0) && LANE_NT == BROOT_THREADS;
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -893,6 +896,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_LDS_TOTAL));
 #endif
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DELTA_LDS_TOTAL));
+    HIPCHK(hipFuncSetAttribute((const void *)boundary_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BROOT_LDS_BYTES));
 #ifdef BGAMD_EXPERIMENTAL
     HIPCHK(hipFuncSetAttribute((const void *)eval_rows_mdelta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS_TOTAL));
     HIPCHK(hipFuncSetAttribute((const void *)root_hidden_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROOT3_LDS_TOTAL));
@@ -1321,6 +1325,7 @@ struct GreedyRun {
     StagedView sv;
     EnvView ev;                            // the env's view as this run's launches take it (ring log: the slots of the step at hand)
     long long cur_step = 0;                // ring log: the env step being played
+    bool root_ready = false;               // the boundary launch of the step before has already run this step's root pass
     const float *b1, *w2, *b2;
 
     int init(bgamd_env *e, int fl, float eps, int prec)
@@ -1334,6 +1339,7 @@ struct GreedyRun {
         sv = env->sv;
         sv.tops = env->tops_base;
         parity = 0;
+        root_ready = false;
         ev = env->v;
         if (env->ring_rows) {
             ev.traj = env->ring_rows; ev.traj_plies = env->ring_steps; ev.traj_ring = env->ring_steps; ev.endrec = env->ring_end;
@@ -1366,15 +1372,17 @@ struct GreedyRun {
         hipLaunchKernelGGL(roots_kernel, grid1(env->v.n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, flags);
         return BGAMD_OK;
     }
-    int step(const StepStreams &ss, bool more)
+    int step(const StepStreams &ss, bool more, bool first_of_run = true)
     {
+        (void)first_of_run;
         const long long n = env->v.n;
         hipStream_t s = ss.gen;
         env->choice[0] = incremental ? ((env->mfma_delta && env->wm_ok[slot]) ? 1 : 0)
                                      : (precision == BGAMD_F32_DENSE ? 2 : precision == BGAMD_F16X2 ? (env->d16 ? 4 : 3) : 5);
         env->choice[1] = !incremental ? 0 : (env->root_f32_mfma ? 3 : (env->root_resident ? 1 : 2));
-        env->choice[2] = (incremental && ss.root != s) ? 1 : 0;
-        if (incremental) {
+        const bool own_root_launch = incremental && !root_ready;
+        env->choice[2] = (own_root_launch && ss.root != s) ? 1 : 0;
+        if (own_root_launch) {
             // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
             // It runs on a second stream beside the doubles plies -- small latency-bound launches that leave
             // most of the chip idle -- and is joined before the incremental kernel.
@@ -1383,6 +1391,9 @@ struct GreedyRun {
                 HIPCHK(hipEventRecord(env->ev_fork, s));
                 HIPCHK(hipStreamWaitEvent(s2, env->ev_fork, 0));
             }
+#if defined(BG_ABL_STEP) && (BG_ABL_STEP & 1)            // ablation (timing only: the values go stale): no root pass after a run's first step
+            if (first_of_run)
+#endif
             {
                 KTimer t(env, s2, 6);
 #ifdef BGAMD_EXPERIMENTAL
@@ -1422,7 +1433,7 @@ struct GreedyRun {
         sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
         hipStream_t se = s;
         if (incremental) {
-            if (ss.root != s) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
+            if (own_root_launch && ss.root != s) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
             KTimer t(env, se, 1);
             // every workgroup first copies W1^T (117 KB) into LDS: small envs get only as many as their rows can use
             long long dblocks = (n * 24 + DELTA_THREADS - 1) / DELTA_THREADS;
@@ -1461,9 +1472,20 @@ struct GreedyRun {
             ev.end_slot = ev.traj_ring ? cur_step % ev.traj_ring : 0;      // the apply half closes the step the last roots began
             if (fused) {
                 next_log_slot();                                           // ... and the roots half begins the next one
-                hipLaunchKernelGGL(boundary_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, sv_next, xv, flags, epsilon);
-            } else
+                root_ready = env->root_in_boundary;
+#ifdef BGAMD_EXPERIMENTAL
+                if (env->root_f32_mfma || !env->root_resident) root_ready = false;          // (the other root passes exist as launches only)
+#endif
+                if (root_ready)
+                    hipLaunchKernelGGL(boundary_kernel<true>, grid1(n, LANE_NT), dim3(LANE_NT), BROOT_LDS_BYTES, s, ev, sv, sv_next, xv, flags, epsilon,
+                                       (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1);
+                else
+                    hipLaunchKernelGGL(boundary_kernel<false>, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, sv_next, xv, flags, epsilon,
+                                       (const uint4 *)nullptr, (const uint2 *)nullptr, (const float *)nullptr);
+            } else {
+                root_ready = false;
                 hipLaunchKernelGGL(apply_kernel, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, xv, flags, epsilon);
+            }
         }
         env->sv.tops = sv.tops;                                // the set whose T_U describes the last evaluated rows
         if (fused) { parity ^= 1; sv = sv_next; }
@@ -1494,7 +1516,7 @@ int bgamd_env_run_greedy(bgamd_env *env, int flags, float epsilon, int precision
     rc = run.begin(s);
     if (rc) return rc;
     for (int64_t step = 0; step < n_steps; ++step) {
-        rc = run.step(ss, step + 1 < n_steps);
+        rc = run.step(ss, step + 1 < n_steps, step == 0);
         if (rc) return rc;
     }
     HIPCHK(hipGetLastError());

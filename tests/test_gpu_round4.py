@@ -273,3 +273,33 @@ def test_pooled_game_dropped_with_work_queued_on_a_side_stream(bg, weights):
     s.synchronize()
     g = bg.Game(0)
     assert g.getGameBoard() == start
+
+
+# ---- the root pass inside the boundary launch ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1000, 33000])
+def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monkeypatch, n):
+    """Inside a run the root pass of step t + 1 runs in the boundary launch of step t (boundary_kernel<true>, bg_root_resident.h): against
+    the same run with the root pass as a launch of its own every step (BGAMD_ROOT_IN_BOUNDARY=0, rounds 1-3) and against single steps
+    (step_greedy: apply, roots and the stand-alone root pass) -- the same games, values and counters to the last bit, on lane counts that
+    leave partial tiles and partial workgroups, with exploration, across run boundaries and with the turn log on."""
+    monkeypatch.delenv("BGAMD_ROOT_IN_BOUNDARY", raising=False)
+    a = bg.VecGame(n, seed=808)
+    monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "0")
+    b = bg.VecGame(n, seed=808)
+    monkeypatch.delenv("BGAMD_ROOT_IN_BOUNDARY", raising=False)
+    c = bg.VecGame(n, seed=808)
+    for e in (a, b, c):
+        e.load_weights(weights)
+    ta, tb = a.record_trajectory(64), b.record_trajectory(64)
+    for k in (1, 2, 9, 30):
+        a.run_greedy(k, epsilon=0.05); b.run_greedy(k, epsilon=0.05)
+        for _ in range(k):
+            c.step_greedy(epsilon=0.05)
+        for x in (b, c):
+            assert torch.equal(a.states(), x.states()) and torch.equal(a.turns(), x.turns()) and torch.equal(a.dice(), x.dice()), k
+            la, lx = a.last_choice(), x.last_choice()
+            assert torch.equal(la["value"], lx["value"]) and torch.equal(la["seq"], lx["seq"]), k
+    assert torch.equal(ta, tb)
+    assert a.stats() == b.stats() == c.stats() and a.stats()["error_flags"] == 0
+    assert a.kernel_choice()["root"] == "root_hidden_resident_kernel"
