@@ -87,6 +87,7 @@ SYMBOLS = [
     ("bgamd_td_step", C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, C.c_float, _P, _P]),
     ("bgamd_td_apply", C.c_int, [_P, _P, _P]),
     ("bgamd_td_replay", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_double, C.c_float, _P]),
+    ("bgamd_td_set_delay", C.c_int, [_P, C.c_int]),
     ("bgamd_td_comm_unique_id", C.c_int, [_P]),
     ("bgamd_td_comm_init", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("bgamd_td_comm_destroy", C.c_int, [_P]),

@@ -133,9 +133,11 @@ class TDLambdaLearner:
             cnt += active.sum()                                     # no host sync inside the loop
         return float(sq.item()), int(cnt.item())
 
-    def replay_stream(self, X, lengths, p1_won, slots: int, batch_scale: float = 1.0):
+    def replay_stream(self, X, lengths, p1_won, slots: int, batch_scale: float = 1.0, delay: int = 0):
         """The streamed replay (DeviceTDLambdaLearner.replay_rows(slots=k), bgamd_td_begin_stream) as a host closed form:
-        slot i replays its queue of games one after another, every step sums the updates of the slots' current turns."""
+        slot i replays its queue of games one after another, every step sums the updates of the slots' current turns.
+        delay = 1: the update of step t is applied one step late (bgamd_td_set_delay): step t + 1 runs on the weights of step t plus the
+        update of step t - 1; the last update is applied after the last step."""
         T, G = X.shape[0], X.shape[1]
         dev, dt = self.theta.device, self.theta.dtype
         lengths = torch.as_tensor(lengths, device=dev).long()
@@ -156,6 +158,7 @@ class TDLambdaLearner:
         e = torch.zeros((k, 25601), dtype=dt, device=dev)
         eW1, eb1, eW2, eb2 = self._split(e)
         sq, cnt = 0.0, 0
+        held = None
         for s in range(n_steps):
             gm, t = game[s], tl[s]
             active = gm >= 0
@@ -175,9 +178,17 @@ class TDLambdaLearner:
             eb1.mul_(lam).add_(db1)
             eW1.baddbmm_(db1[:, :, None], x[:, None, :], beta=lam, alpha=1.0)
             coef = (self.learning_rate * batch_scale * delta.double()).to(dt)
-            self.theta.add_(coef @ e)
+            upd = coef @ e
+            if delay:
+                if held is not None:
+                    self.theta.add_(held)
+                held = upd
+            else:
+                self.theta.add_(upd)
             sq += float((delta.double() ** 2).sum().item())
             cnt += int(active.sum().item())
+        if delay and held is not None:
+            self.theta.add_(held)
         return sq, cnt
 
     def state_dict(self):
@@ -252,6 +263,12 @@ class DeviceTDLambdaLearner:
     def _in_library(self, distributed):
         """the library's own collective serves this replay: the learner has a communicator and the replay is a distributed one"""
         return distributed and getattr(self, "_comm", None) is not None and os.environ.get("BGAMD_TD_TORCH_COLLECTIVE") != "1"
+
+    def set_delay(self, delay: int):
+        """delay = 1: streamed replays through 512 ... 4 096 slots apply the update of step t one step late, and a training step is one launch
+        (bgamd_td_set_delay, include/bgamd.h: a documented deviation, opt-in; 0 = exact)."""
+        self._capi.check(self._lib.bgamd_td_set_delay(self._h, int(delay)), "td_set_delay")
+        self.update_delay = int(delay)
 
     def set_weights(self, weights_flat):
         w = torch.as_tensor(weights_flat, dtype=torch.float32).flatten().to(self.device).contiguous()

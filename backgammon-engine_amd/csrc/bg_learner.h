@@ -1058,10 +1058,74 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_trace_pipe_kernel(TdView v
 // G = slots per workgroup: the host picks the smallest of 1, 2, 4, 8, 16 that needs no more workgroups than there are CUs -- a step of
 // 1 024 slots runs on all 256 CUs with four games each instead of on 128 with eight (its trace pass halves), a step of 4 096 slots keeps
 // the two-launch form with a FULL 32-row tile in the forward pass instead of falling back to three launches.
-template <bool FIRST, int G>
-__global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v, long long t, long long n_active, double alpha, float emul, float ginv,
-                                                                        float cmul, int full)
+// DELAY (round 4, bgamd_td_set_delay): the update of step t is applied one step LATE -- step t + 1 still runs on the weights step t ran on
+// plus the update of step t - 1 -- and then a training step is ONE launch: the reduction of step t - 1's partial sums (td_reduce_kernel's work:
+// 26 MB over 256 partial rows, 6.2 us and two kernel boundaries of the 39 us step) is done by the four waves of every workgroup that idle while
+// waves 0-3 run the forward pass, 128 parameters per workgroup, into the OTHER weight buffer: this launch reads theta / wl3 / the partial sums
+// of step t - 1 and writes th_next / wl3_next / its own partial sums, nobody reads what anybody writes.  A documented deviation (one game no
+// longer reproduces the reference's update step for step): opt-in.
+constexpr int TD_DELAY_SLICE = 128;                                              // parameters (internal order) per workgroup and slice: 4 cache lines
+constexpr int TD_DELAY_SLICES = (TD_LD + TD_DELAY_SLICE - 1) / TD_DELAY_SLICE;   // 201 (the last one reads 64 floats past a row: the next row, or the zeroed tail)
+
+// threads j = 0 .. 255 of a workgroup: float4 f = j & 31 of slice `slice`, partial rows r, r + 8, ... -> red[r][f]; call td_delay_finish after a barrier
+__device__ __forceinline__ void td_delay_gather(const float *__restrict__ part_prev, int n_prev, int slice, int j, td_f32x4 (*red)[32])
 {
+    const int f = j & 31, r = j >> 5;
+    td_f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float *src = part_prev + (long long)slice * TD_DELAY_SLICE + f * 4;
+    // TD_MAX_GROUPS / 8 = 32 rows per thread at most: all of a batch's loads go out before the first add (one round trip per 16 rows, not per row);
+    // the order of the adds is fixed (ascending row): bit-reproducible
+    static_assert(TD_MAX_GROUPS <= 256, "the delayed update's gather is written for <= 256 partial rows");
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        td_f32x4 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = r + 8 * (16 * b + i);
+            x[i] = (td_f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g < n_prev) x[i] = *reinterpret_cast<const td_f32x4 *>(src + (long long)g * TD_LD);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += x[i];
+    }
+    red[r][f] = s;
+}
+// threads j = 0 .. 127: parameter j of the slice: th_next = th_cur + the sum over the 8 row groups (fixed order: bit-reproducible), planes refreshed
+__device__ __forceinline__ void td_delay_finish(const float *__restrict__ th_cur, float *__restrict__ th_next, uint16_t *__restrict__ wl3_next,
+                                                float *__restrict__ w1t_next, int slice, int j, td_f32x4 (*red)[32])
+{
+    const int q = slice * TD_DELAY_SLICE + j;                                    // INTERNAL position
+    float u = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) u += red[g][j >> 2][j & 3];
+    if (q < TD_P) {
+        const int p = td_param_of_internal(q);
+        const float th = th_cur[p] + u;
+        th_next[p] = th;
+        if (q < TD_OFF_B1) {
+            if (w1t_next) w1t_next[q] = th;
+            root3_store_weight(wl3_next, q & (N_HID - 1), q >> 7, th);
+        }
+    }
+}
+
+// after the last step of a delayed replay (and before its first: n_prev = 0 copies): theta_out = th_cur + the update still outstanding
+__global__ __launch_bounds__(256) void td_delay_flush_kernel(const float *__restrict__ part_prev, int n_prev, const float *__restrict__ th_cur,
+                                                             float *__restrict__ th_next, uint16_t *__restrict__ wl3_next, float *__restrict__ w1t_next)
+{
+    __shared__ td_f32x4 red[8][32];
+    td_delay_gather(part_prev, n_prev, blockIdx.x, threadIdx.x, red);
+    __syncthreads();
+    if (threadIdx.x < TD_DELAY_SLICE) td_delay_finish(th_cur, th_next, wl3_next, w1t_next, blockIdx.x, threadIdx.x, red);
+}
+
+template <bool FIRST, int G, bool DELAY = false>
+__global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v, long long t, long long n_active, double alpha, float emul, float ginv,
+                                                                        float cmul, int full, const float *__restrict__ part_prev = nullptr,
+                                                                        int n_prev = 0, float *__restrict__ th_next = nullptr,
+                                                                        uint16_t *__restrict__ wl3_next = nullptr)
+{
+    __shared__ td_f32x4 dred[DELAY ? 8 : 1][32];
     static_assert(TD_WIDE_THREADS == 512 && G >= 1 && G <= 16 && (G & (G - 1)) == 0, "512-thread workgroups, 2 G rows in one 32-row tile");
     __shared__ __attribute__((aligned(16))) float fs[G][TD_FLD];
     __shared__ float cs[G];
@@ -1172,8 +1236,14 @@ __global__ __launch_bounds__(TD_WIDE_THREADS) void td_step_fused_kernel(TdView v
                 const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
                 if (row < 2 * G) sd[row][n] = w2n * hv[j];
             }
+        } else if (DELAY) {
+            // waves 4-7, idle during the forward pass: step t - 1's partial sums -> the weights of step t + 1, one 128-parameter slice
+            // per workgroup (the host takes this route only for launches of >= TD_DELAY_SLICES workgroups)
+            if ((int)blockIdx.x < TD_DELAY_SLICES) td_delay_gather(part_prev, n_prev, blockIdx.x, tid - 256, dred);
         }
-        __syncthreads();                                             // srow, sd
+        __syncthreads();                                             // srow, sd (and the delayed update's row-group sums)
+        if (DELAY && tid >= 256 && tid < 256 + TD_DELAY_SLICE && (int)blockIdx.x < TD_DELAY_SLICES)
+            td_delay_finish(v.theta, th_next, wl3_next, nullptr, blockIdx.x, tid - 256, dred);
         if (tid < G * 16) {                                          // ever-active feature masks: thread = (game, two board points | tail)
             const int g = tid >> 4, q = tid & 15;
             if (i0 + g < n_active) {

@@ -1824,6 +1824,11 @@ struct bgamd_td {
     void *comm = nullptr;                  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     float *d_upd = nullptr;                // [TD_P] the step's update, all-reduced in place
+    // delayed update (bgamd_td_set_delay): the update of step t applied one step late, a training step = ONE launch (bg_learner.h)
+    int delay = 0;
+    float *theta2[2] = {nullptr, nullptr};      // [TD_LD] the weights a step reads / the next step's
+    uint16_t *wl3_2[2] = {nullptr, nullptr};    // their bf16 x 3 planes
+    float *partial2 = nullptr;                 // the second set of partial sums (+ zeroed tail): step t writes set t & 1 (set 0 = v.partial)
     bool timing = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -1938,6 +1943,8 @@ int bgamd_td_destroy(bgamd_td *td)
     for (hipEvent_t e : td->ev) hipEventDestroy(e);
     bgamd_td_comm_destroy(td);
     if (td->d_upd) hipFree(td->d_upd);
+    for (int k = 0; k < 2; ++k) { if (td->theta2[k]) hipFree(td->theta2[k]); if (td->wl3_2[k]) hipFree(td->wl3_2[k]); }
+    if (td->partial2) hipFree(td->partial2);
     delete td;
     return BGAMD_OK;
 }
@@ -2183,10 +2190,106 @@ int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream)
     return BGAMD_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// slots per workgroup of the fused launch for a step of n_active slots (0: the step does not take the fused launch)
+int td_fuse_g_for(const bgamd_td *td, long long n_active)
+{
+    const long long fuse_groups_max = td->n_cu < TD_MAX_GROUPS ? td->n_cu : TD_MAX_GROUPS;
+    int fuse_g = td->fuse_g > 0 ? td->fuse_g : 1;
+    if (td->fuse_g <= 0) while (fuse_g < 16 && (n_active + fuse_g - 1) / fuse_g > fuse_groups_max) fuse_g *= 2;
+    const bool ok = td->fuse_step && td->pipe && td->fused && n_active >= td->direct_min && !td->no_wide_even && n_active >= td->fuse_min &&
+                    n_active < td->mfma_min && n_active < td->nt_min && (n_active + fuse_g - 1) / fuse_g <= fuse_groups_max;
+    return ok ? fuse_g : 0;
+}
+
+// The delayed replay: every step ONE launch of td_step_fused_kernel<., ., DELAY = true> (bg_learner.h).  Step t reads weight buffer t & 1 and the
+// partial sums of step t - 1, writes weight buffer (t + 1) & 1 and its own partial sums (set t & 1); one flush launch at the end applies the last
+// update and leaves the result in the learner's canonical buffers.
+int td_replay_delayed(bgamd_td *td, int64_t n_steps, long long k, int fuse_g, double alpha, float lambda, hipStream_t s)
+{
+    if (!td->theta2[0]) {
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipMalloc((void **)&td->theta2[b], (size_t)TD_LD * 4));
+            HIPCHK(hipMemset(td->theta2[b], 0, (size_t)TD_LD * 4));
+            HIPCHK(hipMalloc((void **)&td->wl3_2[b], 3 * EVAL16_W_BYTES));
+            HIPCHK(hipMemset(td->wl3_2[b], 0, 3 * EVAL16_W_BYTES));
+        }
+        HIPCHK(hipMalloc((void **)&td->partial2, ((size_t)TD_MAX_GROUPS * TD_LD + 64) * 4));
+        HIPCHK(hipMemset(td->partial2, 0, ((size_t)TD_MAX_GROUPS * TD_LD + 64) * 4));
+    }
+    td->last_stream = s;
+    HIPCHK(hipMemcpyAsync(td->theta2[0], td->v.theta, (size_t)TD_LD * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(td->wl3_2[0], td->v.wl3, 3 * EVAL16_W_BYTES, hipMemcpyDeviceToDevice, s));
+    float *part[2] = {td->v.partial, td->partial2};
+    const int n_groups = (int)((k + fuse_g - 1) / fuse_g);
+    for (int64_t t = 0; t < n_steps; ++t) {
+        float emul = lambda, ginv = 1.0f, cmul = 1.0f;                 // (the scale of the stored traces: as bgamd_td_step)
+        int full = 1;
+        if (t == 0) td->scale = 1.0;
+        else {
+            const double c = (double)lambda * td->scale;
+            if (td->lazy && c >= 0x1p-40 && c <= 0x1p40) { td->scale = c; emul = 1.0f; ginv = (float)(1.0 / c); cmul = (float)c; full = 0; }
+            else { emul = (float)c; td->scale = 1.0; }
+        }
+        TdView v = td->v;
+        v.full_step = full;
+        v.theta = td->theta2[t & 1];
+        v.wl3 = td->wl3_2[t & 1];
+        v.partial = part[t & 1];
+        const float *pprev = part[(t + 1) & 1];
+        const int n_prev = t == 0 ? 0 : n_groups;
+        float *thn = td->theta2[(t + 1) & 1];
+        uint16_t *wln = td->wl3_2[(t + 1) & 1];
+#define BG_DELAY_LAUNCH(G)                                                                                                                   \
+    do {                                                                                                                                     \
+        if (t == 0)                                                                                                                          \
+            hipLaunchKernelGGL((td_step_fused_kernel<true, G, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t,           \
+                               (long long)k, alpha, emul, ginv, cmul, 1, pprev, n_prev, thn, wln);                                           \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((td_step_fused_kernel<false, G, true>), dim3(n_groups), dim3(TD_WIDE_THREADS), 0, s, v, (long long)t,          \
+                               (long long)k, alpha, emul, ginv, cmul, full, pprev, n_prev, thn, wln);                                        \
+    } while (0)
+        switch (fuse_g) {
+            case 1: BG_DELAY_LAUNCH(1); break;
+            case 2: BG_DELAY_LAUNCH(2); break;
+            case 4: BG_DELAY_LAUNCH(4); break;
+            case 8: BG_DELAY_LAUNCH(8); break;
+            default: BG_DELAY_LAUNCH(16); break;
+        }
+#undef BG_DELAY_LAUNCH
+    }
+    // the update of the last step is still outstanding: theta = buffer n_steps & 1 + the sum of the last step's partial sums
+    hipLaunchKernelGGL(td_delay_flush_kernel, dim3(TD_DELAY_SLICES), dim3(256), 0, s, (const float *)part[(n_steps + 1) & 1], n_steps ? n_groups : 0,
+                       (const float *)td->theta2[n_steps & 1], td->v.theta, td->v.wl3, td->v.w1t);
+    HIPCHK(hipGetLastError());
+    return BGAMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bgamd_td_set_delay(bgamd_td *td, int delay)
+{
+    if (!td || delay < 0 || delay > 1) return BGAMD_E_INVALID;
+    td->delay = delay;
+    return BGAMD_OK;
+}
+
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream)
 {
     if (!td || !h_n_active || n_steps < 0 || (td->begun && !td->stream_mode && n_steps > td->v.T)) return BGAMD_E_INVALID;
     HIPCHK(hipSetDevice(td->device));
+    if (td->delay && td->begun && td->stream_mode && td->has_weights && n_steps > 0) {
+        // the one-launch step exists for the steps that take the fused launch with at least TD_DELAY_SLICES workgroups: a streamed replay through a
+        // constant number of slots in that range (512 ... 4 096 on 256 CUs).  Anything else replays exactly, update by update.
+        bool same = true;
+        for (int64_t t = 1; t < n_steps; ++t) same = same && h_n_active[t] == h_n_active[0];
+        const long long k = h_n_active[0];
+        const int g = same && k > 0 && k <= td->v.n_games ? td_fuse_g_for(td, k) : 0;
+        if (g > 0 && (k + g - 1) / g >= TD_DELAY_SLICES) return td_replay_delayed(td, n_steps, k, g, alpha, lambda, (hipStream_t)stream);
+    }
     for (int64_t t = 0; t < n_steps; ++t) {
         if (h_n_active[t] == 0) continue;
         const int rc = bgamd_td_step(td, t, h_n_active[t], alpha, lambda, nullptr, stream);

@@ -44,6 +44,7 @@ def run_continuous(a, env, arena, L, group, world, prec, say, n_classic=0, t0=No
     assert a.slots > 0 and not a.host_learner, "--continuous replays streamed through --slots on the device learner"
     dist = torch.distributed if world > 1 else None
     sp = ContinuousSelfPlay(env, ring_steps=a.ring_steps, episode=n_classic)      # (the classic rounds played episodes 0 .. n_classic - 1)
+    L.set_delay(a.update_delay)
     side = torch.cuda.Stream()
     dev = torch.cuda.current_device()
     t0 = time.time() if t0 is None else t0
@@ -148,6 +149,8 @@ def main():
     ap.add_argument("--window-steps", type=int, default=84, help="env steps per window of --continuous (84 steps of n lanes ~ n finished games)")
     ap.add_argument("--ring-steps", type=int, default=1024, help="depth of the ring log of --continuous (games longer than ring - 2 windows are dropped)")
     ap.add_argument("--verbose", action="store_true", help="a line per round / window")
+    ap.add_argument("--update-delay", type=int, default=0, help="1: the device learner applies every update one step late and a training step is ONE launch "
+                    "(bgamd_td_set_delay: a documented deviation; streamed replays through 512 ... 4 096 slots)")
     ap.add_argument("--burn-in-windows", type=int, default=0, help="--continuous: windows played (and not replayed) before the first one that counts: all lanes "
                     "start at ply 0 together, so the games that END in the first windows are the short ones only; after ~3 windows the lanes are out of "
                     "step and a window's finished games are an unbiased sample")
@@ -198,6 +201,8 @@ def main():
     first_dice = None
     n_classic = min(a.classic_rounds, a.rounds) if a.continuous else a.rounds
     for r in range(n_classic):
+        if not a.host_learner:                               # the first --classic-rounds rounds are always replayed exactly (the fragile phase of a run)
+            L.set_delay(a.update_delay if r >= a.classic_rounds else 0)
         games_done = r * a.games * world
         L.update_learning_params(games_done // max(1, a.schedule_div))
         if a.lam is not None:

@@ -314,6 +314,15 @@ int bgamd_td_begin_stream_games(bgamd_td *td, const void *d_rows, int64_t ring_s
 int bgamd_td_step(bgamd_td *td, int64_t t, int64_t n_active, double alpha, float lambda, float *d_update, void *stream);
 int bgamd_td_apply(bgamd_td *td, const float *d_update, void *stream);
 int bgamd_td_replay(bgamd_td *td, int64_t n_steps, const int64_t *h_n_active, double alpha, float lambda, void *stream);
+/* Delayed update, opt-in (delay = 1; 0 = exact, the default): bgamd_td_replay applies the update of step t one step LATE -- step t + 1 runs on
+ * the weights of step t plus the update of step t - 1 -- whenever the replay is a streamed one through a constant number of slots that takes the
+ * fused training step with >= 201 workgroups (512 ... 4 096 slots on 256 CUs; anything else replays exactly).  The step's reduction then has a
+ * whole step to happen in and a training step is ONE launch instead of two (csrc/bg_learner.h: the reduction of step t - 1 rides on the waves
+ * that idle during step t's forward pass).  A documented deviation from train.py:136-170, where every update is applied before the next state
+ * is evaluated: with thousands of games summed per step a one-step delay is a perturbation of the step ORDER, not of what is learned (quality:
+ * profiles/r04_training_quality.txt) -- but ONE game no longer reproduces the reference's update step for step, so fixtures G6 / G9 hold for
+ * delay = 0 only.  bgamd_td_step / bgamd_td_step_allreduce are always exact. */
+int bgamd_td_set_delay(bgamd_td *td, int delay);
 /* ---- the one collective of a multi-rank training step, issued by the library ("one all-reduce of 25 601 fp32 per
  * training step, RCCL over xGMI, in place, on the compute stream"; train.py:536-547 is the loop it scales).  The learner owns an RCCL
  * communicator: rank 0 calls bgamd_td_comm_unique_id, the 128 bytes reach the other ranks by whatever the launcher has

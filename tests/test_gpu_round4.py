@@ -303,3 +303,47 @@ def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monk
     assert torch.equal(ta, tb)
     assert a.stats() == b.stats() == c.stats() and a.stats()["error_flags"] == 0
     assert a.kernel_choice()["root"] == "root_hidden_resident_kernel"
+
+
+# ---- the delayed update: a training step in one launch -----------------------------------------------------------------------------
+
+def test_delayed_update_replay_matches_the_delayed_closed_form(bg, weights):
+    """bgamd_td_set_delay(1): a streamed replay through 512 / 1 024 / 2 048 / 4 096 slots applies the update of step t one step late, the
+    reduction of step t - 1 riding on the idle waves of step t's launch (td_step_fused_kernel<., ., DELAY>).  Against the float64 closed form
+    of the SAME delayed schedule (TDLambdaLearner.replay_stream(delay=1)) within the exact replay's bound; the exact closed form is measurably
+    another trajectory; twice bit-identical; over a game table / ring log as over per-lane rows; a replay that does not qualify (64 slots)
+    is the exact one bit for bit."""
+    from backgammon_env.learner import DeviceTDLambdaLearner, TDLambdaLearner, play_round
+    n = 12288
+    env = bg.VecGame(n, seed=99)
+    env.load_weights(weights)
+    rows, lengths, p1_won = play_round(env, max_plies=400, epsilon=0.1)
+    X = env.encode_rows(rows)
+    for slots in (2048, 1024, 512, 4096):
+        scale = 48.0 / slots
+        L = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+        L.set_delay(1)
+        out = []
+        for rep in range(2):
+            L.set_weights(weights)
+            sq, cnt = L.replay_rows(rows, lengths, p1_won, batch_scale=scale, slots=slots)
+            out.append((_np(L.theta).copy(), sq, cnt))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:] and out[0][2] == int(_np(lengths).sum())
+        Ld = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.8, dtype=torch.float64)
+        Ld.replay_stream(X, lengths, p1_won, slots=slots, batch_scale=scale, delay=1)
+        Le = TDLambdaLearner(weights, device="cuda", alpha=0.1, lam=0.8, dtype=torch.float64)
+        Le.replay_stream(X, lengths, p1_won, slots=slots, batch_scale=scale, delay=0)
+        th_d, th_e = _np(Ld.theta), _np(Le.theta)
+        moved = np.abs(th_d - weights).max()
+        gap, gap_exact = np.abs(out[0][0] - th_d).max(), np.abs(out[0][0] - th_e).max()
+        print("delayed update through %d slots: max |theta - delayed float64 closed form| = %.3g (weights moved %.3g); from the EXACT closed form %.3g"
+              % (slots, gap, moved, gap_exact))
+        assert moved > 1e-3 and gap < 2e-4 * max(1.0, moved)
+        assert gap_exact > 5 * gap                                    # the delay is visible: it is the delayed schedule that was replayed
+    # a replay that does not take the one-launch step is the exact replay
+    A = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+    A.set_delay(1)
+    A.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=64)
+    B = DeviceTDLambdaLearner(weights, max_games=n, alpha=0.1, lam=0.8)
+    B.replay_rows(rows, lengths, p1_won, batch_scale=0.3, slots=64)
+    assert torch.equal(A.theta, B.theta)

@@ -32,6 +32,7 @@ ap.add_argument("--warm", type=int, default=3)
 ap.add_argument("--eps", type=float, default=0.05)
 ap.add_argument("--modes", default="round,round_pipe,cont,cont_pipe")
 ap.add_argument("--priority", type=int, default=0, help="stream priority of the learner's stream (-1 = high)")
+ap.add_argument("--delay", type=int, default=0, help="1: the learner applies every update one step late, a training step is one launch (bgamd_td_set_delay)")
 ap.add_argument("--alpha-scale", type=float, default=96.0, help="games' worth of update per training step")
 a = ap.parse_args()
 w0 = np.fromfile(os.path.join(ROOT, "tests/golden/tdgammonNEW100k.f32"), dtype=np.float32)
@@ -46,6 +47,7 @@ def sync():
 def run(mode):
     env = bg.VecGame(n, seed=5)
     L = DeviceTDLambdaLearner(w0, max_games=max(k, 1), alpha=0.1, lam=0.7)
+    L.set_delay(a.delay)
     side = torch.cuda.Stream(priority=a.priority)
     pipe = mode.endswith("_pipe")
     cont = mode.startswith("cont")
