@@ -410,7 +410,7 @@ class VecGame:
         _capi.check(self._lib.bgamd_env_kernel_choice(self._h, out), "kernel_choice")
         ev = ("eval_rows_delta_kernel", "eval_rows_mdelta_kernel", "eval_rows_f32_kernel", "eval_rows_f16x2_kernel", "eval_rows_d16_kernel",
               "eval_rows_bf16_kernel")
-        rt = (None, "root_hidden_resident_kernel", "root_hidden_bf16x3_kernel", "eval_rows_f32_kernel<root>")
+        rt = (None, "root_hidden_resident_kernel", "root_hidden_bf16x3_kernel", "eval_rows_f32_kernel<root>", "inside boundary_kernel<true>")
         return {"eval": ev[out[0]], "root": rt[out[1]], "root_on_second_stream": bool(out[2]), "experimental_build": bool(out[3])}
 
     def kernel_times(self):

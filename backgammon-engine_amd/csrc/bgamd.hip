@@ -1379,9 +1379,9 @@ struct GreedyRun {
         hipStream_t s = ss.gen;
         env->choice[0] = incremental ? ((env->mfma_delta && env->wm_ok[slot]) ? 1 : 0)
                                      : (precision == BGAMD_F32_DENSE ? 2 : precision == BGAMD_F16X2 ? (env->d16 ? 4 : 3) : 5);
-        env->choice[1] = !incremental ? 0 : (env->root_f32_mfma ? 3 : (env->root_resident ? 1 : 2));
         const bool own_root_launch = incremental && !root_ready;
         env->choice[2] = (own_root_launch && ss.root != s) ? 1 : 0;
+        env->choice[1] = !incremental ? 0 : (!own_root_launch ? 4 : (env->root_f32_mfma ? 3 : (env->root_resident ? 1 : 2)));      // 4: it ran inside the boundary launch before
         if (own_root_launch) {
             // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
             // It runs on a second stream beside the doubles plies -- small latency-bound launches that leave

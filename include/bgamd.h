@@ -254,7 +254,8 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * BGAMD_MFMA_DELTA, BGAMD_F16X2_RESIDENT, BGAMD_ROOT_RESIDENT=0, BGAMD_ROOT_F32, BGAMD_TD_FUSED=0; the default build ignores them).
  * bgamd_env_kernel_choice: what the last greedy step actually launched -- h_out[0] value net: 0 eval_rows_delta_kernel, 1 eval_rows_mdelta_kernel,
  * 2 eval_rows_f32_kernel, 3 eval_rows_f16x2_kernel, 4 eval_rows_d16_kernel, 5 eval_rows_bf16_kernel; h_out[1] root pass: 0 none, 1
- * root_hidden_resident_kernel, 2 root_hidden_bf16x3_kernel, 3 eval_rows_f32_kernel<root>; h_out[2]: 1 = root pass on the env's second
+ * root_hidden_resident_kernel, 2 root_hidden_bf16x3_kernel, 3 eval_rows_f32_kernel<root>, 4 no launch of its own: it ran inside the
+ * boundary launch of the step before (boundary_kernel<true>, every step of a run but the first); h_out[2]: 1 = root pass on the env's second
  * stream; h_out[3]: 1 = experimental build.  bench.py labels its kernels from this, not from the environment. */
 const char *bgamd_build_flags(void);
 int bgamd_env_kernel_choice(bgamd_env *env, int32_t h_out[4]);

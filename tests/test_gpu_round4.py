@@ -302,7 +302,8 @@ def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monk
             assert torch.equal(la["value"], lx["value"]) and torch.equal(la["seq"], lx["seq"]), k
     assert torch.equal(ta, tb)
     assert a.stats() == b.stats() == c.stats() and a.stats()["error_flags"] == 0
-    assert a.kernel_choice()["root"] == "root_hidden_resident_kernel"
+    assert a.kernel_choice()["root"] == "inside boundary_kernel<true>" and not a.kernel_choice()["root_on_second_stream"]
+    assert b.kernel_choice()["root"] == c.kernel_choice()["root"] == "root_hidden_resident_kernel"
 
 
 # ---- the delayed update: a training step in one launch -----------------------------------------------------------------------------

@@ -30,7 +30,7 @@ for r in range(a.rounds):
         d = json.loads(line[-1])
         k = d["kernels"]
         res[n].append((d["ms_per_step"], k["eval"]["avg_ms"], k["leaves"]["avg_ms"], k["expand"]["avg_ms"], k["apply_avg_ms"],
-                       k["eval"].get("root_pass_avg_ms", 0.0)))
+                       k["eval"].get("root_pass_avg_ms") or 0.0))
         print(n, r, res[n][-1], flush=True)
 print("%-14s %9s %9s %9s %9s %9s %9s" % ("variant", "ms/step", "eval", "leaves", "doubles", "boundary", "root"))
 for n in a.names:

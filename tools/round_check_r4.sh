@@ -23,6 +23,15 @@ else
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/pipe_$m -- python3 tools/train_pipeline.py --modes $m --rounds 4 --warm 2 > gpurun_out/$TAG/pipe_${m}_rocprof.log 2>&1
   done
   unset BGAMD_NO_BUILD
+  python tools/pipeline_slowdown.py gpurun_out/$TAG/pipe_cont gpurun_out/$TAG/pipe_cont_pipe > gpurun_out/$TAG/pipeline_kernel_slowdown.txt; cat gpurun_out/$TAG/pipeline_kernel_slowdown.txt
+  python tools/train_pipeline.py --modes cont,cont_pipe --delay 1 > gpurun_out/$TAG/train_pipeline_delay1.txt 2>&1; grep lanes gpurun_out/$TAG/train_pipeline_delay1.txt
+  python tools/lanes_study.py > gpurun_out/$TAG/lanes_study.txt 2>&1; grep lanes gpurun_out/$TAG/lanes_study.txt | cut -c1-250
+  export BGAMD_NO_BUILD=1
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG/lanes_32768_trace -- python3 tools/lanes_study.py --only 32768,f32,nofork > gpurun_out/$TAG/lanes_32768_trace.log 2>&1
+  python tools/lanes_study.py --timeline gpurun_out/$TAG/lanes_32768_trace > gpurun_out/$TAG/lanes_32768_timeline.txt 2>&1; cat gpurun_out/$TAG/lanes_32768_timeline.txt
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG/lanes_32768_trace_bf16 -- python3 tools/lanes_study.py --only 32768,bf16,nofork > gpurun_out/$TAG/lanes_32768_trace_bf16.log 2>&1
+  python tools/lanes_study.py --timeline gpurun_out/$TAG/lanes_32768_trace_bf16 > gpurun_out/$TAG/lanes_32768_timeline_bf16.txt 2>&1; cat gpurun_out/$TAG/lanes_32768_timeline_bf16.txt
+  unset BGAMD_NO_BUILD
   python tools/train_dist_step.py 16384 256 1024 2048 > gpurun_out/$TAG/train_dist_step.txt 2>&1; grep "slots," gpurun_out/$TAG/train_dist_step.txt | cut -c1-400
   python tools/td_bench.py 512 4096 16384 32768 65536 > gpurun_out/$TAG/td_bench.txt 2>&1
   python tools/train_breakdown.py 65536 0 s4096 s2048 s1024 > gpurun_out/$TAG/train_breakdown.txt 2>&1; grep -v amdgpu gpurun_out/$TAG/train_breakdown.txt | cut -c1-200
