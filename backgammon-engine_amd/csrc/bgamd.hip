@@ -803,10 +803,16 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     env->mfma_delta = on("BGAMD_MFMA_DELTA");
     env->d16 = on("BGAMD_F16X2_RESIDENT");
 #endif
-    // the root pass on a second stream pays from ~28 k lanes up (65 536: 0.1510 vs 0.1523 ms per step); below, the fork /
-    // join events cost more than the overlap gives (512 lanes: 0.0675 vs 0.0587 ms, 16 384: 0.0851 vs 0.0802)
-    env->root_in_boundary = !(getenv("BGAMD_ROOT_IN_BOUNDARY") != nullptr && atoi(getenv("BGAMD_ROOT_IN_BOUNDARY")) == 0) && LANE_NT == BROOT_THREADS;
-    env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && (n_games >= 28672 || getenv("BGAMD_OVERLAP") != nullptr);
+    // Where the root pass runs (round 4, profiles/r04_lanes_32768_anatomy.txt): inside the boundary launch from 49 152 lanes (65 536: 142.1 vs 142.8 us per
+    // step) -- a boundary workgroup owns 256 games, so a smaller env has too few of them to spread the pass over the chip (16 384 lanes: 77.1 vs 70.4 us,
+    // 32 768: 98.7 vs 97.5) and keeps it as a launch of its own -- and never on a second stream unless asked (BGAMD_OVERLAP=1): since the resident root pass
+    // the fork is worth nothing at any size (16 384: 72.4 vs 70.4 us the other way, 32 768: 98.1 vs 97.5, 65 536: 143.2 vs 142.8).
+    // BGAMD_ROOT_IN_BOUNDARY=0 / =1 force either.
+    {
+        const char *rib = getenv("BGAMD_ROOT_IN_BOUNDARY");
+        env->root_in_boundary = (rib ? atoi(rib) != 0 : n_games >= 49152) && LANE_NT == BROOT_THREADS;
+    }
+    env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && getenv("BGAMD_OVERLAP") != nullptr && atoi(getenv("BGAMD_OVERLAP")) != 0;
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess) {

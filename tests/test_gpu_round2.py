@@ -180,17 +180,17 @@ def test_delta_list_worst_case_and_overflow_flag(bg, O, weights):
 # ---- the headline configuration: 65 536 lanes, second-stream root pass, fused boundaries -------------------------------
 
 def test_greedy_65536_sampled_lanes_vs_oracle(bg, O, weights):
-    """At 65 536 lanes the root pass runs on the env's second stream (fork after the roots, join before the value
-    net) and run_greedy fuses apply(t) + roots(t+1).  Sampled lanes are checked against the oracle after ONE
-    step_greedy and after run_greedy(8); an env with BGAMD_NO_OVERLAP=1 (everything on one stream) must stay
-    bit-identical to the overlapped one throughout."""
+    """At 65 536 lanes run_greedy fuses apply(t) + roots(t+1) + (round 4) the value net's root pass of step t + 1 into one launch, everything
+    on the caller's stream.  Sampled lanes are checked against the oracle after ONE step_greedy and after run_greedy(8); an env with rounds
+    1-3's launch structure (the root pass a launch of its own, forked onto the env's second stream: BGAMD_ROOT_IN_BOUNDARY=0 + BGAMD_OVERLAP=1)
+    must stay bit-identical to it throughout."""
     n = 65536
     a = bg.VecGame(n, seed=777)
-    os.environ["BGAMD_NO_OVERLAP"] = "1"
+    os.environ["BGAMD_ROOT_IN_BOUNDARY"] = "0"; os.environ["BGAMD_OVERLAP"] = "1"
     try:
         b = bg.VecGame(n, seed=777)
     finally:
-        del os.environ["BGAMD_NO_OVERLAP"]
+        del os.environ["BGAMD_ROOT_IN_BOUNDARY"]; del os.environ["BGAMD_OVERLAP"]
     a.load_weights(weights); b.load_weights(weights)
     a.run_greedy(30); b.run_greedy(30)
     lanes = list(range(5, n, 257))                            # 255 lanes

@@ -18,29 +18,32 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "backgammon-engine_amd")]
 def timeline(d):
     import collections, csv, glob
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("bg::", ""),
-                    r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda x: x[0])
+    def short(n):
+        return n.replace("(anonymous namespace)::", "").replace("bg::", "").replace("void ", "").split("(")[0].split("<")[0]
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda x: x[0])
+    first = "boundary_kernel" if any(r[2] == "boundary_kernel" for r in rows) else "roots_kernel"     # (the dense value-net modes: roots / apply are launches of their own)
     steps, cur = [], None
     for s, e, name, full in rows:
-        if name == "boundary_kernel":
+        if name == first:
             if cur:
                 steps.append(cur)
             cur = [(s, e, name)]
         elif cur is not None:
             cur.append((s, e, "expand_kernel<LEAF>" if name == "expand_kernel" else name))
-    steps = [st for st in steps if len(st) == 5 and (st[-1][1] - st[0][0]) < 400000][-200:]
+    want = 4 if first == "boundary_kernel" else 0
+    steps = [st for st in steps if (len(st) == want or (not want and 5 <= len(st) <= 7)) and (st[-1][1] - st[0][0]) < 400000][-200:]
     agg = collections.defaultdict(list)
     for st in steps:
         t0 = st[0][0]
         for s, e, name in st:
             agg[name].append((s - t0, e - t0))
     nxt = [b[0][0] - a[0][0] for a, b in zip(steps, steps[1:]) if b[0][0] - a[0][0] < 400000]
-    print(f"{len(steps)} steady-state steps; mean start / end of each kernel in us from the boundary launch's start (rocprof stretches the gaps):")
+    print(f"{len(steps)} steady-state steps; mean start / end of each kernel in us from the start of {first} (rocprof stretches the gaps):")
     for name, v in sorted(agg.items(), key=lambda kv: sum(x[0] for x in kv[1]) / len(kv[1])):
         print("  %-34s %7.1f .. %7.1f   (%.1f us)" % (name, sum(x[0] for x in v) / len(v) / 1e3, sum(x[1] for x in v) / len(v) / 1e3,
                                                     sum(x[1] - x[0] for x in v) / len(v) / 1e3))
     if nxt:
-        print("  next boundary launch               %7.1f" % (sum(nxt) / len(nxt) / 1e3))
+        print("  next %-29s %7.1f" % (first, sum(nxt) / len(nxt) / 1e3))
 
 
 def main():
