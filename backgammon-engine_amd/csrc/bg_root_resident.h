@@ -112,12 +112,19 @@ __global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
 // hand: it goes on with THEIR root pass -- 8 tiles of 32 games, wave c = hidden units 32 c .. 32 c + 31, the same operands, the same MFMA
 // sequence per accumulator (K-step ascending; planes hi, mid, lo inside a step) and the same epilogue as root_hidden_resident_kernel:
 // the same bits.  Rows come from LDS (the roots half of the launch puts them there), no launch, no event, no round trip.
-constexpr int BROOT_THREADS = 256;                           // = LANE_NT of the boundary launch: four waves, 8 tiles of 32 games
-constexpr int BROOT_TILES = BROOT_THREADS / 32;
+constexpr int BROOT_THREADS = 256;                           // = LANE_NT of the boundary launch: four waves
+// games per workgroup of the boundary launch when it carries the root pass: 128 -- half the threads idle through the lane-per-game halves, 4 tiles per
+// workgroup, two workgroups per CU at 65 536 lanes and one on EVERY CU at 32 768 (-DBG_BROOT_GPW=256: a game per thread, 8 tiles; same-box A/B:
+// 65 536 lanes 0.1432 vs 0.1429 ms per step, 32 768 lanes 0.0945 vs 0.0994)
+#ifndef BG_BROOT_GPW
+#define BG_BROOT_GPW 128
+#endif
+constexpr int BROOT_GPW = BG_BROOT_GPW;
+constexpr int BROOT_TILES = BROOT_GPW / 32;
 // all 8 tiles' A operands are staged at once (one block barrier, then 8 x 39 MFMAs per wave back to back): a first version that staged
 // tile by tile behind a barrier each -- root_hidden_resident_kernel's loop -- cost the launch 16.7 us (a chain of 8 x (LDS round trip,
 // 39 dependent MFMAs, stores, barrier) on one wave per SIMD) where the MFMAs are 4.8
-constexpr int BROOT_LDS_BYTES = BROOT_TILES * D16_XBUF_U4 * 16 + EVAL16_LUT_BYTES + BROOT_THREADS * 32;
+constexpr int BROOT_LDS_BYTES = BROOT_TILES * D16_XBUF_U4 * 16 + EVAL16_LUT_BYTES + BROOT_GPW * 32;
 
 struct BRootWeights { uint4 w[3][K16_STEPS]; };              // wave c's three bf16 planes of hidden units 32 c .. 32 c + 31: 156 registers
 
@@ -142,16 +149,18 @@ __device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4
     extern __shared__ uint4 sBR[];
     uint4 *sX = sBR;                                                      // [8 tiles][13][64]
     uint2 *sLut = reinterpret_cast<uint2 *>(sX + BROOT_TILES * D16_XBUF_U4);
-    uint4 *sRows = reinterpret_cast<uint4 *>(sLut + 16);                  // [256][2]
+    uint4 *sRows = reinterpret_cast<uint4 *>(sLut + 16);                  // [games per workgroup][2]
     if (threadIdx.x < 16) sLut[threadIdx.x] = lut[threadIdx.x];
-    sRows[2 * threadIdx.x] = row0;
-    sRows[2 * threadIdx.x + 1] = row1;
+    if (threadIdx.x < BROOT_GPW) {
+        sRows[2 * threadIdx.x] = row0;
+        sRows[2 * threadIdx.x + 1] = row1;
+    }
     const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
     constexpr float NL2E = -1.44269504088896340736f;
     const float bb = b1[32 * c + r];
     long long left = n_games - g0;
-    const int n_tiles = left <= 0 ? 0 : (int)((left < BROOT_THREADS ? left : BROOT_THREADS) + 31) >> 5;     // workgroup-uniform
+    const int n_tiles = left <= 0 ? 0 : (int)((left < BROOT_GPW ? left : BROOT_GPW) + 31) >> 5;     // workgroup-uniform
     __syncthreads();
     // the A operands wave c decodes for a tile: K-steps c, c + 4, c + 8, and the tail step for wave 0 (exactly root_hidden_resident_kernel's)
     for (int tile = 0; tile < n_tiles; ++tile) {

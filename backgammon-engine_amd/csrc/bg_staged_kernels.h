@@ -473,12 +473,14 @@ __global__ __launch_bounds__(LANE_NT) void apply_kernel(EnvView e, StagedView sv
 // ROOT: the workgroup goes on with the value net's root pass of step t + 1 for its 256 games (bg_root_resident.h: the same bits as
 // root_hidden_resident_kernel; needs LANE_NT == 256 and BROOT_LDS_BYTES of dynamic LDS) -- the step then has no root-pass launch
 template <bool ROOT>
-__global__ __launch_bounds__(LANE_NT) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
+__global__ __launch_bounds__(LANE_NT, 2) void boundary_kernel(EnvView e, StagedView sv, StagedView sv_next, ExploreView xv, int flags,
                                                            float epsilon, const uint4 *__restrict__ wl3, const uint2 *__restrict__ lut,
                                                            const float *__restrict__ b1)
 {
     static_assert(!ROOT || LANE_NT == BROOT_THREADS, "the in-launch root pass is written for 256-thread workgroups");
-    const long long g = (long long)blockIdx.x * LANE_NT + threadIdx.x;
+    // with the root pass a workgroup owns BROOT_GPW games (the threads past them idle through the lane-per-game halves: g = n is no lane of the env)
+    constexpr int GPW = ROOT ? BROOT_GPW : LANE_NT;
+    const long long g = (int)threadIdx.x < GPW ? (long long)blockIdx.x * GPW + threadIdx.x : e.n;
     LaneCtx next;                                       // the lane's new state goes on in registers: no read-back
     apply_body(e, sv, xv, flags, epsilon, g, &next);
     __syncthreads();                                    // finish_turn's statistics scratch is free again
@@ -486,5 +488,5 @@ __global__ __launch_bounds__(LANE_NT) void boundary_kernel(EnvView e, StagedView
     BRootWeights wf;
     if (ROOT) broot_load_weights(wl3, wf);
     roots_body(e, sv_next, flags, g, &next, ROOT ? row : nullptr);
-    if (ROOT) boundary_root_pass(wf, row[0], row[1], (long long)blockIdx.x * LANE_NT, e.n, lut, b1, sv_next.root_hidden);
+    if (ROOT) boundary_root_pass(wf, row[0], row[1], (long long)blockIdx.x * GPW, e.n, lut, b1, sv_next.root_hidden);
 }

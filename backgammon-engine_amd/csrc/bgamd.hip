@@ -803,14 +803,14 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
     env->mfma_delta = on("BGAMD_MFMA_DELTA");
     env->d16 = on("BGAMD_F16X2_RESIDENT");
 #endif
-    // Where the root pass runs (round 4, profiles/r04_lanes_32768_anatomy.txt): inside the boundary launch from 49 152 lanes (65 536: 142.1 vs 142.8 us per
-    // step) -- a boundary workgroup owns 256 games, so a smaller env has too few of them to spread the pass over the chip (16 384 lanes: 77.1 vs 70.4 us,
-    // 32 768: 98.7 vs 97.5) and keeps it as a launch of its own -- and never on a second stream unless asked (BGAMD_OVERLAP=1): since the resident root pass
-    // the fork is worth nothing at any size (16 384: 72.4 vs 70.4 us the other way, 32 768: 98.1 vs 97.5, 65 536: 143.2 vs 142.8).
+    // Where the root pass runs (round 4, profiles/r04_lanes_32768_anatomy.txt, r04_ab_root_pass_in_boundary.txt): inside the boundary launch from 24 576 lanes
+    // -- there a boundary workgroup owns 128 games (BROOT_GPW), so 32 768 lanes still put a workgroup on every CU: 94.5 vs 98.7 us per step with the pass as a
+    // launch of its own (65 536: 143.2 vs 143.6; 16 384: 72.0 vs 71.7, a tie: smaller envs keep the launch) -- and never on a second stream unless asked
+    // (BGAMD_OVERLAP=1): since the resident root pass the fork is worth nothing at any size (16 384: 76.5 vs 70.5 us the other way, 32 768: 101.1 vs 97.5).
     // BGAMD_ROOT_IN_BOUNDARY=0 / =1 force either.
     {
         const char *rib = getenv("BGAMD_ROOT_IN_BOUNDARY");
-        env->root_in_boundary = (rib ? atoi(rib) != 0 : n_games >= 49152) && LANE_NT == BROOT_THREADS;
+        env->root_in_boundary = (rib ? atoi(rib) != 0 : n_games >= 24576) && LANE_NT == BROOT_THREADS;
     }
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && getenv("BGAMD_OVERLAP") != nullptr && atoi(getenv("BGAMD_OVERLAP")) != 0;
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
@@ -1483,7 +1483,7 @@ struct GreedyRun {
                 if (env->root_f32_mfma || !env->root_resident) root_ready = false;          // (the other root passes exist as launches only)
 #endif
                 if (root_ready)
-                    hipLaunchKernelGGL(boundary_kernel<true>, grid1(n, LANE_NT), dim3(LANE_NT), BROOT_LDS_BYTES, s, ev, sv, sv_next, xv, flags, epsilon,
+                    hipLaunchKernelGGL(boundary_kernel<true>, grid1(n, BROOT_GPW), dim3(LANE_NT), BROOT_LDS_BYTES, s, ev, sv, sv_next, xv, flags, epsilon,
                                        (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1);
                 else
                     hipLaunchKernelGGL(boundary_kernel<false>, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, sv_next, xv, flags, epsilon,

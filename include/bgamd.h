@@ -247,7 +247,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
  * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
  * 4 roots+expand (plies 1-3), 5 leaf stage, 6 root term of the incremental value net when it is a launch of its own (the first step of a run; every step of an env
- * below 49 152 lanes or with BGAMD_ROOT_IN_BOUNDARY=0 -- otherwise it runs inside the boundary launch, slot 2; BGAMD_OVERLAP=1 forks the launch onto the env's
+ * below 24 576 lanes or with BGAMD_ROOT_IN_BOUNDARY=0 -- otherwise it runs inside the boundary launch, slot 2; BGAMD_OVERLAP=1 forks the launch onto the env's
  * second stream beside the doubles plies, rounds 1-3's default).  enable: 0 = off, 1 = every group, (mask << 8) | (stride << 20) = only the groups
  * whose bit is set in mask, on every stride-th launch of a group (0 = every launch; an event pair costs ~4 us of
  * stream time, so a timed run samples). */

@@ -283,7 +283,7 @@ def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monk
     the same run with the root pass as a launch of its own every step (BGAMD_ROOT_IN_BOUNDARY=0, rounds 1-3) and against single steps
     (step_greedy: apply, roots and the stand-alone root pass) -- the same games, values and counters to the last bit, on lane counts that
     leave partial tiles and partial workgroups, with exploration, across run boundaries and with the turn log on."""
-    monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "1")        # (the default from 49 152 lanes; below, the pass stays a launch of its own: forced here)
+    monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "1")        # (the default from 24 576 lanes; below, the pass stays a launch of its own: forced here)
     a = bg.VecGame(n, seed=808)
     monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "0")
     b = bg.VecGame(n, seed=808)
