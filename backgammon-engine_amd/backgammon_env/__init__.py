@@ -405,13 +405,14 @@ class VecGame:
 
     def kernel_choice(self):
         """What the last greedy step launched (bgamd_env_kernel_choice): names of the value-net kernel and of the root pass, whether the root
-        pass ran on the env's second stream, and whether the library is the experimental build."""
+        pass ran on the env's second stream, the kernel(s) of the expansion below the roots, and whether the library is the experimental build."""
         out = (C.c_int32 * 4)()
         _capi.check(self._lib.bgamd_env_kernel_choice(self._h, out), "kernel_choice")
         ev = ("eval_rows_delta_kernel", "eval_rows_mdelta_kernel", "eval_rows_f32_kernel", "eval_rows_f16x2_kernel", "eval_rows_d16_kernel",
               "eval_rows_bf16_kernel")
         rt = (None, "root_hidden_resident_kernel", "root_hidden_bf16x3_kernel", "eval_rows_f32_kernel<root>", "inside boundary_kernel<true>")
-        return {"eval": ev[out[0]], "root": rt[out[1]], "root_on_second_stream": bool(out[2]), "experimental_build": bool(out[3])}
+        return {"eval": ev[out[0]], "root": rt[out[1]], "root_on_second_stream": bool(out[2] & 1),
+                "expand": "expand_all_kernel" if out[2] & 2 else "doubles_kernel + expand_kernel<LEAF>", "experimental_build": bool(out[3])}
 
     def kernel_times(self):
         ms, n = (C.c_double * 8)(), (C.c_uint64 * 8)()

@@ -31,9 +31,26 @@ __host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
 
 struct Node { uint32_t game, key; };
 
+// A block barrier that orders LDS traffic only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. every wave
+// first waits for its global stores to be acknowledged (s_waitcnt vmcnt(0)).  The expansion phases synchronise on LDS records between
+// writing rows that nobody in the launch reads back: with this barrier the stores drain behind the next phase's work.
+__device__ __forceinline__ void barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+template <bool LDS_ONLY>
+__device__ __forceinline__ void block_barrier()
+{
+    if (LDS_ONLY) barrier_lds();
+    else __syncthreads();
+}
+
 // ---- workgroup exclusive scan (NW waves); returns the prefix, *total = sum over the block ----
 // LEAD_SYNC = false: the caller guarantees a barrier since the last read of s_wave / s_slot
-template <int NW = 4, bool LEAD_SYNC = true>
+// LDS_ONLY: the barriers order LDS only (above)
+template <int NW = 4, bool LEAD_SYNC = true, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *s_wave /*[NW]*/)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -43,9 +60,9 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
         const uint32_t t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    if (LEAD_SYNC) __syncthreads();        // s_wave may still be read by the previous scan
+    if (LEAD_SYNC) block_barrier<LDS_ONLY>();        // s_wave may still be read by the previous scan
     if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
+    block_barrier<LDS_ONLY>();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -58,12 +75,12 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
 }
 
 // bump allocation of `total` entries for the whole block (thread 0 does the atomic)
-template <bool LEAD_SYNC = true>
+template <bool LEAD_SYNC = true, bool LDS_ONLY = false>
 __device__ __forceinline__ unsigned long long block_alloc(unsigned long long *top, uint32_t total, unsigned long long *s_slot)
 {
-    if (LEAD_SYNC) __syncthreads();
+    if (LEAD_SYNC) block_barrier<LDS_ONLY>();
     if (threadIdx.x == 0) *s_slot = total ? atomicAdd(top, (unsigned long long)total) : 0ull;
-    __syncthreads();
+    block_barrier<LDS_ONLY>();
     return *s_slot;
 }
 
@@ -91,6 +108,8 @@ __device__ __forceinline__ void block_alloc2(unsigned long long *topA, uint32_t 
 struct StagedView {
     Node *d1, *d2, *f;                    // node lists
     long long cap_d1, cap_d2, cap_f;
+    Node *f2;                             // leaf parents of the doubles turns when one launch expands everything (expand_all_kernel)
+    long long cap_f2;
     uint4 *u_rows;                        // unique rows
     uint2 *u_info;
     long long cap_rows;
@@ -105,6 +124,6 @@ struct StagedView {
 #ifndef BG_CTR_STRIDE
 #define BG_CTR_STRIDE 16
 #endif
-enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_COUNT = 4 * BG_CTR_STRIDE };
+enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_F2 = 4 * BG_CTR_STRIDE, T_COUNT = 5 * BG_CTR_STRIDE };
 
 }  // namespace bg

@@ -168,30 +168,64 @@ __device__ __forceinline__ void node_fetch(const EnvView &e, const Node *__restr
     }
 }
 
+// where the doubles plies put their leaf parents: the shared F list (one ply per launch / doubles_kernel) or the doubles
+// workgroups' own F2 list (expand_all_kernel, whose other workgroups are reading F at the same time)
+struct LeafParents { Node *list; unsigned long long *top; unsigned long long cap; };
+__device__ __forceinline__ LeafParents leaf_parents_shared(const StagedView &sv)
+{
+    return LeafParents{sv.f, &sv.tops[T_F], (unsigned long long)sv.cap_f};
+}
+
 // One block iteration: every thread brings its node (threads >= np never have one).  Returns (block-uniform) where the
 // children went: *out_base / *out_total in the MODE's output list.  All threads of the block must call it.
-template <int MODE, int NT>
-__device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const NodeIn &x, int np,
-                                             unsigned long long *out_base, uint32_t *out_total)
+// STUCK_ROWS (MODE_PLY2): a stuck ply-2 node -- a leaf parent whose only "successor" is itself -- is written as its row right
+// here instead of going through the leaf-parent list (*out_stuck = how many: they count as leaf parents and as rows).
+// the phase's LDS records: ONE instance per kernel, declared by the kernel and shared by all its phases (every phase ends with a
+// block barrier); as function-local statics every instantiation of expand_phase inlined into a kernel took its own 70 B per thread
+template <int NT>
+struct ExpandLds {
+    uint32_t par_plane[8][NT];         // parent position: mover's planes 0-3, opponent's 4-7
+    uint32_t par_game[NT], par_key[NT];                    // key | die<<27 | turn<<31
+    uint16_t child[NT * 15];           // successor q of the workgroup: parent << 5 | origin (31: the parent itself)
+    uint32_t wave[NT / 64];
+    unsigned long long slot;
+};
+// A node handed from one phase to the next IN REGISTERS (expand_all_kernel's doubles workgroups): the lane that built successor q
+// of one phase is the node thread of the next -- no node list, no allocation, no reload of the game's planes, no replay of the key
+struct ChainNode {
+    Side own, opp, pown, popp;         // the node's position (mover's side, opponent's) and the position before its last move
+    uint32_t game, key;
+    int pl, die;
+    bool valid;
+};
+
+// The phase proper.  The node's position comes in registers: s (after the key's moves), prev_* (before the last of them), root_pl (the
+// game's planes as stored: the non-doubles rule of the leaf stage asks the root position).
+// CHAIN (MODE_PLY2 / MODE_PLY3): successors q < NT are handed to the caller in *chain (lane q gets successor q), only the successors
+// from NT on go through the MODE's output list: *out_base / *out_total describe THAT part, *out_all counts all of them.
+template <int MODE, int NT, bool STUCK_ROWS, bool CHAIN>
+__device__ __forceinline__ void expand_phase_core(const EnvView &e, const StagedView &sv, bool valid, const Node nd, const NodeState &s,
+                                                  const Side &prev_own, const Side &prev_opp, const uint32_t (&root_pl)[8],
+                                                  unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
+                                                  ExpandLds<NT> &L, uint32_t *out_stuck, ChainNode *chain, uint32_t *out_all)
 {
+    static_assert(!STUCK_ROWS || MODE == MODE_PLY2, "only the ply-2 phase has stuck nodes of its own");
+    static_assert(!CHAIN || MODE != MODE_LEAF, "the leaf stage's successors are rows");
+    uint32_t (&s_par_plane)[8][NT] = L.par_plane;
+    uint32_t (&s_par_game)[NT] = L.par_game, (&s_par_key)[NT] = L.par_key;
+    uint16_t (&s_child)[NT * 15] = L.child;
+    uint32_t (&s_wave)[NT / 64] = L.wave;
+    unsigned long long &s_slot = L.slot;
     constexpr int NW = NT / 64;
-    (void)np;
-    __shared__ uint32_t s_par_plane[8][NT];    // parent position: mover's planes 0-3, opponent's 4-7
-    __shared__ uint32_t s_par_game[NT], s_par_key[NT];     // key | die<<27 | turn<<31
-    __shared__ uint16_t s_child[NT * 15];                  // successor q of the workgroup: parent << 5 | origin (31: the parent itself)
-    __shared__ uint32_t s_wave[NW];
-    __shared__ unsigned long long s_slot;
-    const bool valid = x.valid;
+#if defined(BG_PHASE_FULL_BARRIERS) && BG_PHASE_FULL_BARRIERS
+    constexpr bool PH_LDS = false;
+#else
+    constexpr bool PH_LDS = true;
+#endif
     uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
     uint32_t succ = 0;                     // their origins
-    const Node nd = x.nd;
     if (valid) {
-        const uint32_t (&pl_next)[8] = x.pl;
-        const uint32_t meta = x.meta;
-        NodeState s;
         uint32_t m0 = 0;
-        Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
-        node_build(nd, pl_next, meta, s, &prev_own, &prev_opp);
         {
             const int die = (s.len & 1) ? s.dB : s.dA;
             if (s.len < (s.dbl ? 4 : 2)) m0 = legal_origins(s.own, s.opp, s.pl, die);
@@ -202,7 +236,7 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
                     // produced (y, x) -- the same two checker moves, the same landing points, hence the same
                     // afterstate under a smaller key.  Such successors are not generated.
                     Side rown, ropp;
-                    split_sides(pl_next, s.pl, rown, ropp);
+                    split_sides(root_pl, s.pl, rown, ropp);
                     const int x = key_origin(nd.key, 0);
                     const uint32_t ma_root = legal_origins(rown, ropp, s.pl, s.dB);
                     uint32_t cand = m0 & ma_root, dup = 0;
@@ -267,7 +301,9 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
         }
     }
     uint32_t total, totB = 0;
-    const uint32_t off = block_scan_256<NW, true>(cnt, &total, s_wave);
+    // (the phase's barriers order LDS only -- barrier_lds(), BG_PHASE_FULL_BARRIERS=1: __syncthreads() everywhere -- except the last
+    //  one of a phase whose successors the workgroup's next phase fetches from the list)
+    const uint32_t off = block_scan_256<NW, true, PH_LDS>(cnt, &total, s_wave);
     {   // the node names its successors: the lane that builds successor q reads (parent, origin) in one access instead
         // of searching the offsets and stepping through the mask
         uint16_t *c = s_child + off;
@@ -275,20 +311,41 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
         if (succ == 0 && cnt) *c = (uint16_t)(tag | 31u);
         while (succ) { const int o = __ffs(succ) - 1; succ &= succ - 1; *c++ = (uint16_t)(tag | (uint32_t)o); }
     }
-    unsigned long long *topA = &sv.tops[MODE == MODE_PLY2 ? T_D2 : (MODE == MODE_PLY3 ? T_F : T_U)];
-    const unsigned long long capA = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d2 : (MODE == MODE_PLY3 ? sv.cap_f : sv.cap_rows));
-    const unsigned long long baseA = block_alloc<false>(topA, total, &s_slot);      // the scan just synchronised
-    bool ok = baseA + total <= capA;
+    // what goes through the output list: everything, or (CHAIN) the successors past the first NT
+    const uint32_t listed = CHAIN ? (total > (uint32_t)NT ? total - (uint32_t)NT : 0u) : total;
+    const uint32_t q0 = CHAIN ? (uint32_t)NT : 0u;             // first successor that does
+    unsigned long long *topA = MODE == MODE_PLY2 ? &sv.tops[T_D2] : (MODE == MODE_PLY3 ? lp.top : &sv.tops[T_U]);
+    const unsigned long long capA = MODE == MODE_PLY2 ? (unsigned long long)sv.cap_d2 : (MODE == MODE_PLY3 ? lp.cap : (unsigned long long)sv.cap_rows);
+    const unsigned long long baseA = block_alloc<false, PH_LDS>(topA, listed, &s_slot);     // the scan just synchronised
+    bool ok = baseA + listed <= capA;
     if (MODE == MODE_PLY2) {                               // stuck doubles nodes are leaf parents as they are
-        const uint32_t offB = block_scan_256<NW, true>(cntB, &totB, s_wave);
-        const unsigned long long baseB = block_alloc(&sv.tops[T_F], totB, &s_slot);
-        ok = ok && baseB + totB <= (unsigned long long)sv.cap_f;
-        if (ok && cntB) sv.f[baseB + offB] = Node{nd.game, nd.key};
+        const uint32_t offB = block_scan_256<NW, true, PH_LDS>(cntB, &totB, s_wave);
+        if (STUCK_ROWS) {
+            const unsigned long long baseB = block_alloc<true, PH_LDS>(&sv.tops[T_U], totB, &s_slot);
+            ok = ok && baseB + totB <= (unsigned long long)sv.cap_rows;
+            if (ok && cntB) {                              // the row of the node's own position (what the leaf stage writes for o == 31)
+                const unsigned long long d = baseB + offB;
+                const uint32_t pk = s_par_key[threadIdx.x];
+                const int pl = (int)(pk >> 31);
+                const int a0 = pl ? 4 : 0, b0 = pl ? 0 : 4;
+                sv.u_rows[2 * d] = make_uint4(s_par_plane[a0][threadIdx.x] | (pl ? TURN_BIT : 0u), s_par_plane[a0 + 1][threadIdx.x],
+                                              s_par_plane[a0 + 2][threadIdx.x], s_par_plane[a0 + 3][threadIdx.x]);
+                sv.u_rows[2 * d + 1] = make_uint4(s_par_plane[b0][threadIdx.x], s_par_plane[b0 + 1][threadIdx.x], s_par_plane[b0 + 2][threadIdx.x],
+                                                  s_par_plane[b0 + 3][threadIdx.x]);
+                sv.u_info[d] = make_uint2(nd.game, nd.key | (pl ? 0x80000000u : 0u));
+            }
+        } else {
+            const unsigned long long baseB = block_alloc<true, PH_LDS>(lp.top, totB, &s_slot);
+            ok = ok && baseB + totB <= lp.cap;
+            if (ok && cntB) lp.list[baseB + offB] = Node{nd.game, nd.key};
+        }
+        if (out_stuck) *out_stuck = ok ? totB : 0u;
     }
     if (!ok) flag_overflow(e);
-    __syncthreads();                                       // parent records and offsets are in place
+    block_barrier<PH_LDS>();                               // parent records and offsets are in place
+    if (CHAIN) chain->valid = false;
     if (ok) {
-        for (uint32_t q = threadIdx.x; q < total; q += NT) {
+        for (uint32_t q = CHAIN ? threadIdx.x : threadIdx.x + q0; q < total; q += NT) {
             const uint32_t ce = s_child[q];
             const int par = (int)(ce >> 5), o = (int)(ce & 31u);
             const uint32_t pk = s_par_key[par];
@@ -296,24 +353,64 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
             Side a{{s_par_plane[0][par], s_par_plane[1][par], s_par_plane[2][par], s_par_plane[3][par]}};
             Side b{{s_par_plane[4][par], s_par_plane[5][par], s_par_plane[6][par], s_par_plane[7][par]}};
             uint32_t key = pk & KEY_MASK;
+            const uint32_t game = s_par_game[par];
+            if (CHAIN && q < (uint32_t)NT) {                   // (q == threadIdx.x) this lane's node of the next phase
+                chain->pown = a; chain->popp = b;
+                if (o != 31) { apply_move(a, b, pl, o, die); key = key_child(key, o); }
+                chain->own = a; chain->opp = b; chain->game = game; chain->key = key; chain->pl = pl; chain->die = die;
+                chain->valid = true;
+                continue;
+            }
             if (o != 31) {
                 apply_move(a, b, pl, o, die);
                 key = key_child(key, o);
             }
-            const uint32_t game = s_par_game[par];
-            const unsigned long long d = baseA + q;
+            const unsigned long long d = baseA + (q - q0);
             if (MODE == MODE_LEAF) {
                 const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
                 sv.u_rows[2 * d] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
                 sv.u_rows[2 * d + 1] = make_uint4(s2.b[0], s2.b[1], s2.b[2], s2.b[3]);
                 sv.u_info[d] = make_uint2(game, key | (pl ? 0x80000000u : 0u));
             } else if (MODE == MODE_PLY2) sv.d2[d] = Node{game, key};
-            else sv.f[d] = Node{game, key};
+            else lp.list[d] = Node{game, key};
         }
     }
-    __syncthreads();                                       // the records are reused by the next phase; its reads of what
-    *out_base = baseA;                                     // this one wrote to global memory come after this barrier
-    *out_total = ok ? total : 0u;
+    // the records are reused by the next phase; where that phase fetches what this one wrote to a list (one ply per phase: not the
+    // rows, not the register hand-off) its reads come after a barrier that has waited for the stores
+    block_barrier<PH_LDS && (MODE == MODE_LEAF || CHAIN)>();
+    *out_base = baseA;
+    *out_total = ok ? listed : 0u;
+    if (out_all) *out_all = ok ? total : 0u;
+}
+
+// ... with the node fetched from a list: its position is rebuilt from the game's planes by replaying the key
+template <int MODE, int NT, bool STUCK_ROWS = false, bool CHAIN = false>
+__device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const NodeIn &x, int np,
+                                             unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
+                                             ExpandLds<NT> &L, uint32_t *out_stuck = nullptr, ChainNode *chain = nullptr,
+                                             uint32_t *out_all = nullptr)
+{
+    (void)np;
+    NodeState s;
+    s.own = s.opp = Side{{0, 0, 0, 0}};
+    s.pl = 0; s.dA = s.dB = 1; s.len = 0; s.dbl = false;
+    Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
+    if (x.valid) node_build(x.nd, x.pl, x.meta, s, &prev_own, &prev_opp);
+    expand_phase_core<MODE, NT, STUCK_ROWS, CHAIN>(e, sv, x.valid, x.nd, s, prev_own, prev_opp, x.pl, out_base, out_total, lp, L, out_stuck,
+                                                   chain, out_all);
+}
+
+// ... with the node handed over in registers by the phase before (doubles turns only: the die is the same at every ply)
+template <int MODE, int NT>
+__device__ __forceinline__ void expand_phase_chained(const EnvView &e, const StagedView &sv, const ChainNode &n,
+                                                     unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
+                                                     ExpandLds<NT> &L, ChainNode *chain, uint32_t *out_all)
+{
+    NodeState s;
+    s.own = n.own; s.opp = n.opp; s.pl = n.pl; s.dA = s.dB = n.die; s.dbl = true; s.len = key_len(n.key);
+    const uint32_t no_root[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (only the non-doubles rule reads the root)
+    expand_phase_core<MODE, NT, false, MODE != MODE_LEAF>(e, sv, n.valid, Node{n.game, n.key}, s, n.pown, n.popp, no_root, out_base, out_total,
+                                                          lp, L, nullptr, chain, out_all);
 }
 
 // nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole grid,
@@ -330,6 +427,7 @@ template <int MODE>
 __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e, StagedView sv)
 {
     constexpr int NT = expand_threads(MODE);
+    __shared__ ExpandLds<NT> L;
     const Node *in = MODE == MODE_PLY2 ? sv.d1 : (MODE == MODE_PLY3 ? sv.d2 : sv.f);
     const unsigned long long cap_in = (unsigned long long)(MODE == MODE_PLY2 ? sv.cap_d1 : (MODE == MODE_PLY3 ? sv.cap_d2 : sv.cap_f));
     unsigned long long n_in = sv.tops[MODE == MODE_PLY2 ? T_D1 : (MODE == MODE_PLY3 ? T_D2 : T_F)];
@@ -355,7 +453,7 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
         node_fetch(e, in, nb * NPB < n_in ? idx_of(nb) : -1ll, nxt);
         unsigned long long base;
         uint32_t total;
-        expand_phase<MODE, NT>(e, sv, cur, (int)NPB, &base, &total);
+        expand_phase<MODE, NT>(e, sv, cur, (int)NPB, &base, &total, leaf_parents_shared(sv), L);
         staged_total += total;
         cur = nxt;
     }
@@ -368,6 +466,7 @@ __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e,
 __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvView e, StagedView sv)
 {
     constexpr int NT = expand_threads(MODE_PLY2);
+    __shared__ ExpandLds<NT> L;
     unsigned long long n_in = sv.tops[T_D1];
     if (n_in > (unsigned long long)sv.cap_d1) n_in = (unsigned long long)sv.cap_d1;
     const unsigned long long NPB = nodes_per_block(n_in, NT / 4);
@@ -378,15 +477,123 @@ __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvV
         uint32_t total2;
         NodeIn x2;
         node_fetch(e, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
-        expand_phase<MODE_PLY2, NT>(e, sv, x2, (int)NPB, &base2, &total2);
+        expand_phase<MODE_PLY2, NT>(e, sv, x2, (int)NPB, &base2, &total2, leaf_parents_shared(sv), L);
         for (uint32_t c = 0; c < total2; c += NT) {
             const unsigned long long n3 = total2 - c < (uint32_t)NT ? total2 - c : (uint32_t)NT;
             unsigned long long base3;
             uint32_t total3;
             NodeIn x3;
             node_fetch(e, sv.d2, threadIdx.x < n3 ? (long long)(base2 + c + threadIdx.x) : -1ll, x3);
-            expand_phase<MODE_PLY3, NT>(e, sv, x3, NT, &base3, &total3);
+            expand_phase<MODE_PLY3, NT>(e, sv, x3, NT, &base3, &total3, leaf_parents_shared(sv), L);
         }
+    }
+}
+
+// The whole expansion below the roots in ONE launch (round 4; the default: BGAMD_EXPAND_MERGED=0 brings the two launches back).
+// The doubles plies (28 k + 45 k nodes at 65 536 lanes) are a chain of latencies that leaves most of the chip idle, and the leaf
+// stage of the NON-doubles turns -- three fifths of the leaf stage -- does not depend on them: its parents are written by the roots.
+//   workgroups [0, n_dbl)       a share of the doubles turns' ply-1 nodes through ply 2, ply 3 AND their leaf stage, one phase
+//                               after the other on the workgroup's own allocations (leaf parents in F2, rows in the common arena);
+//   workgroups [n_dbl, grid)    the leaf stage over F, which in this mode holds nothing but the roots' output.
+// No workgroup waits for another.  The rows are the same rows, in another order of the arena -- nothing depends on that order
+// (a row's value is a function of the row; the arg-max keeps the smallest key).
+#ifndef BG_XALL_NT
+#define BG_XALL_NT 512
+#endif
+constexpr int XALL_NT = BG_XALL_NT;
+__global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, StagedView sv, unsigned n_dbl, unsigned dbl_npb, unsigned parts)
+{
+    constexpr int NT = XALL_NT;
+    __shared__ ExpandLds<NT> L;
+    unsigned long long staged_total = 0, fnodes = 0, dnodes = 0;
+    // the first n_dbl workgroups take the doubles turns, the others the non-doubles leaf stage.  (Every workgroup taking a share of both
+    // kinds -- the same mix everywhere -- was measured too: 32-37 us against 29.4: the two kinds overlap when they share a CU as
+    // different workgroups, and follow one another inside one.)
+    // (parts: timing experiments only -- bit 0: the doubles turns, bit 1: the non-doubles leaf stage; 3 = the whole step)
+    const bool do_dbl = blockIdx.x < n_dbl && (parts & 1u), do_leaf = blockIdx.x >= n_dbl && (parts & 2u);
+    const unsigned long long d_first = blockIdx.x, d_stride = n_dbl;
+    const unsigned long long l_first = blockIdx.x - n_dbl, l_stride = gridDim.x - n_dbl;
+    if (do_dbl) {
+        const LeafParents lp{sv.f2, &sv.tops[T_F2], (unsigned long long)sv.cap_f2};
+        unsigned long long n_in = sv.tops[T_D1];
+        if (n_in > (unsigned long long)sv.cap_d1) n_in = (unsigned long long)sv.cap_d1;
+        if (d_first == 0) dnodes = n_in;
+        unsigned long long NPB = (n_in + d_stride - 1) / d_stride;
+        NPB = NPB < 1 ? 1 : (NPB > (unsigned long long)dbl_npb ? (unsigned long long)dbl_npb : NPB);           // (dbl_npb <= NT)
+        // leaf stage over a range of the workgroup's own F2 entries (successors that did not fit the register hand-off)
+        auto leaf_range = [&](unsigned long long base, uint32_t n) {
+            for (uint32_t c4 = 0; c4 < n; c4 += NT) {
+                const unsigned long long n4 = n - c4 < (uint32_t)NT ? n - c4 : (uint32_t)NT;
+                unsigned long long base4;
+                uint32_t total4;
+                NodeIn x4;
+                node_fetch(e, sv.f2, threadIdx.x < n4 ? (long long)(base + c4 + threadIdx.x) : -1ll, x4);
+                expand_phase<MODE_LEAF, NT>(e, sv, x4, NT, &base4, &total4, lp, L);
+                staged_total += total4;
+            }
+        };
+        for (unsigned long long blk = d_first; blk * NPB < n_in; blk += d_stride) {
+            const unsigned long long first = blk * NPB;
+            const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
+            // ply 2 from the roots' list; its first NT successors go on in registers, lane q with successor q ...
+            unsigned long long over2_base, over3_base, base4;
+            uint32_t over2, over3, all2, all3, total4, stuck2;
+            NodeIn x2;
+            ChainNode n3, n4;
+            node_fetch(e, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
+            expand_phase<MODE_PLY2, NT, true, true>(e, sv, x2, (int)NPB, &over2_base, &over2, lp, L, &stuck2, &n3, &all2);
+            dnodes += all2;
+            fnodes += stuck2;
+            staged_total += stuck2;
+            // ... ply 3 on those, the same way, then their leaf stage
+            expand_phase_chained<MODE_PLY3, NT>(e, sv, n3, &over3_base, &over3, lp, L, &n4, &all3);
+            fnodes += all3;
+            expand_phase_chained<MODE_LEAF, NT>(e, sv, n4, &base4, &total4, lp, L, nullptr, nullptr);
+            staged_total += total4;
+            if (over2 | over3) __syncthreads();                // (block-uniform) listed successors: their stores have to have landed
+            leaf_range(over3_base, over3);                     // ply-3 successors past the first NT: through F2
+            for (uint32_t c = 0; c < over2; c += NT) {          // ply-2 successors past the first NT: through D2, one ply per phase
+                const unsigned long long n3c = over2 - c < (uint32_t)NT ? over2 - c : (uint32_t)NT;
+                unsigned long long base3;
+                uint32_t total3;
+                NodeIn x3;
+                node_fetch(e, sv.d2, threadIdx.x < n3c ? (long long)(over2_base + c + threadIdx.x) : -1ll, x3);
+                expand_phase<MODE_PLY3, NT>(e, sv, x3, NT, &base3, &total3, lp, L);
+                fnodes += total3;
+                leaf_range(base3, total3);
+            }
+        }
+    }
+    if (do_leaf) {
+        unsigned long long n_in = sv.tops[T_F];
+        if (n_in > (unsigned long long)sv.cap_f) n_in = (unsigned long long)sv.cap_f;
+        if (l_first == 0) fnodes += n_in;
+        // a contiguous share per workgroup, cut into equal phases of at most NT parents (645 parents are 2 x 323, not 512 + 133: a phase
+        // costs its latencies whatever it holds, and equal shares end together)
+        const unsigned long long share = (n_in + l_stride - 1) / l_stride;
+        const unsigned long long lo = l_first * share < n_in ? l_first * share : n_in;
+        const unsigned long long hi = lo + share < n_in ? lo + share : n_in;
+        const unsigned long long chunks = (hi - lo + NT - 1) / NT;
+        const unsigned long long per = chunks ? (hi - lo + chunks - 1) / chunks : 0;
+        auto idx_of = [&](unsigned long long c) -> long long {
+            const unsigned long long node = lo + c * per + threadIdx.x;
+            return (c < chunks && threadIdx.x < per && node < hi) ? (long long)node : -1ll;
+        };
+        NodeIn cur, nxt;
+        node_fetch(e, sv.f, idx_of(0), cur);
+        for (unsigned long long c = 0; c < chunks; ++c) {
+            node_fetch(e, sv.f, idx_of(c + 1), nxt);
+            unsigned long long base;
+            uint32_t total;
+            expand_phase<MODE_LEAF, NT>(e, sv, cur, (int)per, &base, &total, leaf_parents_shared(sv), L);
+            staged_total += total;
+            cur = nxt;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
+        if (fnodes) atomicAdd(&e.counters[C_FNODES], fnodes);
+        if (dnodes) atomicAdd(&e.counters[C_DNODES], dnodes);
     }
 }
 

@@ -670,6 +670,11 @@ struct bgamd_env {
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
     int choice[4] = {0, 0, 0, 0};           // kernels of the last greedy step (bgamd_env_kernel_choice)
+    bool expand_merged = true;             // doubles plies + leaf stage in one launch (expand_all_kernel); BGAMD_EXPAND_MERGED=0: two launches
+    int expand_parts = 3;                  // timing experiments (BGAMD_EXPAND_PARTS): 1 = only the doubles turns are expanded, 2 = only the others
+    int expand_dbl_npb = 128;              // ply-1 nodes a doubles workgroup takes per iteration (BGAMD_EXPAND_DBL_NPB: 64 .. 512)
+    int expand_dbl_pct = 50;               // share of that launch's workgroups that takes the doubles turns (BGAMD_EXPAND_DBL_PCT: 5 .. 95), the others
+                                           // take the non-doubles leaf stage: one of each kind per CU at 50
     bool root_in_boundary = true;          // inside a run the root pass of step t + 1 runs in the boundary launch of step t (bg_root_resident.h);
                                            //   BGAMD_ROOT_IN_BOUNDARY=0: a launch of its own every step, as up to round 3
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
@@ -812,6 +817,16 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         const char *rib = getenv("BGAMD_ROOT_IN_BOUNDARY");
         env->root_in_boundary = (rib ? atoi(rib) != 0 : n_games >= 24576) && LANE_NT == BROOT_THREADS;
     }
+    {
+        const char *xm = getenv("BGAMD_EXPAND_MERGED");
+        env->expand_merged = xm ? atoi(xm) != 0 : true;
+        const char *xp = getenv("BGAMD_EXPAND_DBL_PCT");
+        if (xp && atoi(xp) >= 5 && atoi(xp) <= 95) env->expand_dbl_pct = atoi(xp);
+        const char *xq = getenv("BGAMD_EXPAND_PARTS");
+        if (xq && atoi(xq) >= 1 && atoi(xq) <= 3) env->expand_parts = atoi(xq);
+        const char *xn = getenv("BGAMD_EXPAND_DBL_NPB");
+        if (xn && atoi(xn) >= 64 && atoi(xn) <= XALL_NT) env->expand_dbl_npb = atoi(xn) & ~63;
+    }
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && getenv("BGAMD_OVERLAP") != nullptr && atoi(getenv("BGAMD_OVERLAP")) != 0;
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -876,6 +891,8 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&sv.d1, (size_t)sv.cap_d1 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.d2, (size_t)sv.cap_d2 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
+        sv.cap_f2 = sv.cap_f;
+        HIPCHK(hipMalloc(&sv.f2, (size_t)sv.cap_f2 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.u_rows, (size_t)cap * 32));
         HIPCHK(hipMalloc(&sv.u_info, (size_t)cap * sizeof(uint2)));
         // an overflowing step (flagged, raised by stats) leaves holes in the arena: they must name a valid game
@@ -917,7 +934,7 @@ int bgamd_env_destroy(bgamd_env *env)
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
                     v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_wd16[0], env->d_wd16[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
-                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
+                    env->sv.d1, env->sv.d2, env->sv.f, env->sv.f2, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     if (env->d_scalar) hipFree(env->d_scalar);
     if (env->d_tmp) hipFree(env->d_tmp);
@@ -1386,7 +1403,7 @@ struct GreedyRun {
         env->choice[0] = incremental ? ((env->mfma_delta && env->wm_ok[slot]) ? 1 : 0)
                                      : (precision == BGAMD_F32_DENSE ? 2 : precision == BGAMD_F16X2 ? (env->d16 ? 4 : 3) : 5);
         const bool own_root_launch = incremental && !root_ready;
-        env->choice[2] = (own_root_launch && ss.root != s) ? 1 : 0;
+        env->choice[2] = ((own_root_launch && ss.root != s) ? 1 : 0) | (env->expand_merged ? 2 : 0);
         env->choice[1] = !incremental ? 0 : (!own_root_launch ? 4 : (env->root_f32_mfma ? 3 : (env->root_resident ? 1 : 2)));      // 4: it ran inside the boundary launch before
         if (own_root_launch) {
             // The value net's root pass (one dense W1 x + b1 per GAME) needs only the root rows the roots just wrote.
@@ -1426,13 +1443,29 @@ struct GreedyRun {
             }
             if (s2 != s) HIPCHK(hipEventRecord(env->ev_join, s2));
         }
-        {
-            KTimer t(env, s, 4);
-            hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, ev, sv);
-        }
-        {
+        if (env->expand_merged) {
+            // one launch: the doubles turns' plies 2, 3 and leaf stage on the first workgroups, the non-doubles leaf stage on the others
+            // (two 512-thread workgroups per CU are resident: one of each kind per CU at the default share)
             KTimer t(env, s, 5);
-            hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, ev, sv);
+            const long long slots = 2ll * ss.n_cu;
+            long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
+            const long long nd_lim = slots * env->expand_dbl_pct / 100;
+            nd = nd < 1 ? 1 : (nd > nd_lim ? nd_lim : nd);
+            long long nl = (n * 16 + XALL_NT - 1) / XALL_NT;
+            const long long nl_lim = slots - nd_lim < 1 ? 1 : slots - nd_lim;
+            nl = nl < 1 ? 1 : (nl > nl_lim ? nl_lim : nl);
+            const long long grid = nd + nl;
+            hipLaunchKernelGGL(expand_all_kernel, dim3((unsigned)grid), dim3(XALL_NT), 0, s, ev, sv, (unsigned)nd,
+                               (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts);
+        } else {
+            {
+                KTimer t(env, s, 4);
+                hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, ev, sv);
+            }
+            {
+                KTimer t(env, s, 5);
+                hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, ev, sv);
+            }
         }
         const bool fused = more && incremental;                // the dense kernels do not clear the other counter set
         StagedView sv_next = sv;

@@ -390,8 +390,10 @@ def main():
         eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
         # algorithmic bytes: leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
         # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
-        leaves_gbs = (fn_l * 52 + u_l * 40) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
-        expand_gbs = (steps_l * 52 + (fn_l + 2 * dn_l) * 8 + dn_l * 44) / (per["expand"] * 1e-3) / 1e9 if per["expand"] else 0.0
+        merged = choice["expand"] == "expand_all_kernel"      # one launch for the doubles plies AND the leaf stage: both byte counts, one time
+        dbl_bytes = (fn_l + 2 * dn_l) * 8 + dn_l * 44
+        leaves_gbs = (fn_l * 52 + u_l * 40 + (dbl_bytes if merged else 0)) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
+        expand_gbs = (steps_l * 52 + dbl_bytes) / (per["expand"] * 1e-3) / 1e9 if per["expand"] and not merged else 0.0
         ks_l = st.get("ksteps_executed", 0) / nl
         peak = PEAK["f32" if a.precision == "f32_dense" else a.precision]
         ev = {"bound": "mfma", "achieved": round(eval_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(eval_tf / peak, 4),
@@ -448,9 +450,9 @@ def main():
                                "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"})
         roofs = {
             "eval": ev,
-            "leaves": {"kernel": "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
+            "leaves": {"kernel": "expand_all_kernel (doubles plies 2+3 and every leaf stage)" if merged else "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
                        "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
-            "expand": {"kernel": "doubles_kernel (plies 2+3 of the doubles turns)", "bound": "hbm", "achieved": round(expand_gbs, 2),
+            "expand": {"kernel": "(inside expand_all_kernel)" if merged else "doubles_kernel (plies 2+3 of the doubles turns)", "bound": "hbm", "achieved": round(expand_gbs, 2),
                        "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
                        "avg_ms": round(per["expand"], 4)},
         }
@@ -459,7 +461,7 @@ def main():
         for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-                for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_kernel<3>")):
+                for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_all_kernel" if merged else "expand_kernel<3>")):
                     if key in pmc:
                         roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
                         roofs[name]["traffic_source"] = f"profiles/{pmc_file} (bytes per launch; a committed PMC pass of this kernel, not measured in this run)"

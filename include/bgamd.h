@@ -256,8 +256,10 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * bgamd_env_kernel_choice: what the last greedy step actually launched -- h_out[0] value net: 0 eval_rows_delta_kernel, 1 eval_rows_mdelta_kernel,
  * 2 eval_rows_f32_kernel, 3 eval_rows_f16x2_kernel, 4 eval_rows_d16_kernel, 5 eval_rows_bf16_kernel; h_out[1] root pass: 0 none, 1
  * root_hidden_resident_kernel, 2 root_hidden_bf16x3_kernel, 3 eval_rows_f32_kernel<root>, 4 no launch of its own: it ran inside the
- * boundary launch of the step before (boundary_kernel<true>, every step of a run but the first); h_out[2]: 1 = root pass on the env's second
- * stream; h_out[3]: 1 = experimental build.  bench.py labels its kernels from this, not from the environment. */
+ * boundary launch of the step before (boundary_kernel<true>, every step of a run but the first); h_out[2]: bit 0 = root pass on the env's
+ * second stream, bit 1 = the expansion below the roots (doubles plies 2-3 + leaf stage) ran as ONE launch (expand_all_kernel; the default,
+ * BGAMD_EXPAND_MERGED=0 brings doubles_kernel + expand_kernel<LEAF> back); h_out[3]: 1 = experimental build.  bench.py labels its kernels
+ * from this, not from the environment. */
 const char *bgamd_build_flags(void);
 int bgamd_env_kernel_choice(bgamd_env *env, int32_t h_out[4]);
 int bgamd_env_time_kernels(bgamd_env *env, int enable);

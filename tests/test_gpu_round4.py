@@ -306,6 +306,46 @@ def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monk
     assert b.kernel_choice()["root"] == c.kernel_choice()["root"] == "root_hidden_resident_kernel"
 
 
+# ---- the expansion below the roots in one launch --------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [700, 33000])
+def test_expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, n):
+    """expand_all_kernel (the default): the doubles turns' plies 2 and 3 AND their leaf stage on the first workgroups of a launch whose
+    other workgroups are the non-doubles leaf stage -- against doubles_kernel + expand_kernel<LEAF> (BGAMD_EXPAND_MERGED=0, rounds 1-4):
+    the rows are the same rows in another order of the arena, so the games, the chosen values and sequences, the turn log and every
+    counter are equal to the last bit; the staged rows of a step are the same multiset; with exploration, across run boundaries, at
+    two shares of doubles workgroups."""
+    monkeypatch.setenv("BGAMD_EXPAND_MERGED", "1")
+    a = bg.VecGame(n, seed=4242)
+    monkeypatch.setenv("BGAMD_EXPAND_DBL_PCT", "25")
+    c = bg.VecGame(n, seed=4242)
+    monkeypatch.delenv("BGAMD_EXPAND_DBL_PCT", raising=False)
+    monkeypatch.setenv("BGAMD_EXPAND_MERGED", "0")
+    b = bg.VecGame(n, seed=4242)
+    monkeypatch.delenv("BGAMD_EXPAND_MERGED", raising=False)
+    for e in (a, b, c):
+        e.load_weights(weights)
+    ta, tb = a.record_trajectory(96), b.record_trajectory(96)
+    for k in (1, 2, 9, 30, 50):
+        for e in (a, b, c):
+            e.run_greedy(k, epsilon=0.05)
+        for x in (b, c):
+            assert torch.equal(a.states(), x.states()) and torch.equal(a.turns(), x.turns()) and torch.equal(a.dice(), x.dice()), k
+            la, lx = a.last_choice(), x.last_choice()
+            assert torch.equal(la["value"], lx["value"]) and torch.equal(la["seq"], lx["seq"]), k
+        # the rows the value net saw in the last step: the same (game, key, afterstate, value) records, in another order of the arena
+        rec = []
+        for e in (a, b):
+            info, st, val = e.unique_rows()
+            r = torch.cat([info, st.to(torch.int64), val.view(torch.int32).to(torch.int64).view(-1, 1)], 1)
+            order = torch.argsort(info[:, 0] * (1 << 32) + info[:, 1], stable=True)
+            rec.append(r[order])
+        assert rec[0].shape == rec[1].shape and torch.equal(rec[0], rec[1]), k
+    assert torch.equal(ta, tb)
+    assert a.stats() == b.stats() == c.stats() and a.stats()["error_flags"] == 0
+    assert a.kernel_choice()["expand"] == "expand_all_kernel" and b.kernel_choice()["expand"] == "doubles_kernel + expand_kernel<LEAF>"
+
+
 # ---- the delayed update: a training step in one launch -----------------------------------------------------------------------------
 
 def test_delayed_update_replay_matches_the_delayed_closed_form(bg, weights):
