@@ -197,6 +197,7 @@ struct ChainNode {
     uint32_t game, key;
     int pl, die;
     bool valid;
+    bool hit;                          // a move of the key has hit a blot (the row's delta list is longer by two entries per hit)
 };
 
 // The phase proper.  The node's position comes in registers: s (after the key's moves), prev_* (before the last of them), root_pl (the
@@ -205,7 +206,7 @@ struct ChainNode {
 // from NT on go through the MODE's output list: *out_base / *out_total describe THAT part, *out_all counts all of them.
 template <int MODE, int NT, bool STUCK_ROWS, bool CHAIN>
 __device__ __forceinline__ void expand_phase_core(const EnvView &e, const StagedView &sv, bool valid, const Node nd, const NodeState &s,
-                                                  const Side &prev_own, const Side &prev_opp, const uint32_t (&root_pl)[8],
+                                                  const Side &prev_own, const Side &prev_opp, const uint32_t (&root_pl)[8], bool prefix_hit,
                                                   unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
                                                   ExpandLds<NT> &L, uint32_t *out_stuck, ChainNode *chain, uint32_t *out_all)
 {
@@ -222,8 +223,16 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
 #else
     constexpr bool PH_LDS = true;
 #endif
-    uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F
-    uint32_t succ = 0;                     // their origins
+    // Leaf stage: the rows of a phase leave in two runs -- first the successors whose moves hit no blot, then the others.  The value net
+    // works 64 consecutive rows per wave for as many gather passes as the LONGEST delta list among them, and a hit is what makes a list
+    // longer (two entries: the blot's point and the bar); the class costs one mask per node here, and the two counts share one scan.
+#if defined(BG_LEAF_CLASSES) && !BG_LEAF_CLASSES
+    constexpr bool CLASSES = false;
+#else
+    constexpr bool CLASSES = MODE == MODE_LEAF;
+#endif
+    uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F; (leaf stage) successors of the second run
+    uint32_t succ = 0, succ_hit = 0;       // their origins; (leaf stage) those of the second run
     if (valid) {
         uint32_t m0 = 0;
         {
@@ -296,21 +305,43 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s_par_plane[k][threadIdx.x] = s.own.b[k]; s_par_plane[4 + k][threadIdx.x] = s.opp.b[k]; }
                 succ = m0;
+                if (CLASSES) {                                 // origins whose move lands on a blot: exactly one opposing checker on the landing point
+                    const uint32_t blots = s.opp.b[0] & ~(s.opp.b[1] | s.opp.b[2] | s.opp.b[3]) & PTS;
+                    succ_hit = m0 & (s.pl ? (blots << die) : (blots >> die));
+                    if (prefix_hit) succ_hit = m0;
+                    cntB = m0 ? (uint32_t)__popc(succ_hit) : ((stuck && prefix_hit) ? 1u : 0u);
+                }
                 s_par_game[threadIdx.x] = nd.game;
-                s_par_key[threadIdx.x] = nd.key | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
+                s_par_key[threadIdx.x] = nd.key | (prefix_hit ? 0x01000000u : 0u) | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
         }
     }
     uint32_t total, totB = 0;
     // (the phase's barriers order LDS only -- barrier_lds(), BG_PHASE_FULL_BARRIERS=1: __syncthreads() everywhere -- except the last
     //  one of a phase whose successors the workgroup's next phase fetches from the list)
-    const uint32_t off = block_scan_256<NW, true, PH_LDS>(cnt, &total, s_wave);
-    {   // the node names its successors: the lane that builds successor q reads (parent, origin) in one access instead
+    uint32_t off;
+    if (CLASSES) {                         // one scan for both runs: first-run count in the low half, second-run count in the high half (<= 7 680 each)
+        uint32_t tot2;
+        const uint32_t off2 = block_scan_256<NW, true, PH_LDS>((cnt - cntB) | (cntB << 16), &tot2, s_wave);
+        const uint32_t totA = tot2 & 0xFFFFu;
+        total = totA + (tot2 >> 16);
+        uint16_t *ca = s_child + (off2 & 0xFFFFu), *cb = s_child + totA + (off2 >> 16);
+        const uint32_t tag = threadIdx.x << 5;
+        if (succ == 0 && cnt) *(cntB ? cb : ca) = (uint16_t)(tag | 31u);
+        uint32_t sa = succ & ~succ_hit, sb = succ & succ_hit;
+        while (sa) { const int o = __ffs(sa) - 1; sa &= sa - 1; *ca++ = (uint16_t)(tag | (uint32_t)o); }
+        while (sb) { const int o = __ffs(sb) - 1; sb &= sb - 1; *cb++ = (uint16_t)(tag | (uint32_t)o); }
+        off = 0;
+        cntB = 0;
+    } else {
+        off = block_scan_256<NW, true, PH_LDS>(cnt, &total, s_wave);
+        // the node names its successors: the lane that builds successor q reads (parent, origin) in one access instead
         // of searching the offsets and stepping through the mask
         uint16_t *c = s_child + off;
         const uint32_t tag = threadIdx.x << 5;
         if (succ == 0 && cnt) *c = (uint16_t)(tag | 31u);
         while (succ) { const int o = __ffs(succ) - 1; succ &= succ - 1; *c++ = (uint16_t)(tag | (uint32_t)o); }
     }
+    (void)off;
     // what goes through the output list: everything, or (CHAIN) the successors past the first NT
     const uint32_t listed = CHAIN ? (total > (uint32_t)NT ? total - (uint32_t)NT : 0u) : total;
     const uint32_t q0 = CHAIN ? (uint32_t)NT : 0u;             // first successor that does
@@ -356,7 +387,14 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
             const uint32_t game = s_par_game[par];
             if (CHAIN && q < (uint32_t)NT) {                   // (q == threadIdx.x) this lane's node of the next phase
                 chain->pown = a; chain->popp = b;
-                if (o != 31) { apply_move(a, b, pl, o, die); key = key_child(key, o); }
+                bool hit = (pk & 0x01000000u) != 0;
+                if (o != 31) {
+                    const int dest = pl ? o - die : o + die;           // a blot on the landing point (points 1 .. 24 only)
+                    if (dest >= 1 && dest <= 24) hit = hit || (((b.b[0] & ~(b.b[1] | b.b[2] | b.b[3])) >> dest) & 1u);
+                    apply_move(a, b, pl, o, die);
+                    key = key_child(key, o);
+                }
+                chain->hit = hit;
                 chain->own = a; chain->opp = b; chain->game = game; chain->key = key; chain->pl = pl; chain->die = die;
                 chain->valid = true;
                 continue;
@@ -395,9 +433,17 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
     s.own = s.opp = Side{{0, 0, 0, 0}};
     s.pl = 0; s.dA = s.dB = 1; s.len = 0; s.dbl = false;
     Side prev_own{{0, 0, 0, 0}}, prev_opp{{0, 0, 0, 0}};
-    if (x.valid) node_build(x.nd, x.pl, x.meta, s, &prev_own, &prev_opp);
-    expand_phase_core<MODE, NT, STUCK_ROWS, CHAIN>(e, sv, x.valid, x.nd, s, prev_own, prev_opp, x.pl, out_base, out_total, lp, L, out_stuck,
-                                                   chain, out_all);
+    bool prefix_hit = false;
+    if (x.valid) {
+        node_build(x.nd, x.pl, x.meta, s, &prev_own, &prev_opp);
+        // has a move of the key hit a blot?  Then the opponent's bar counter is not the root's.
+        Side rown, ropp;
+        split_sides(x.pl, s.pl, rown, ropp);
+        const int bar = s.pl ? 0 : 25;
+        prefix_hit = ((((s.opp.b[0] ^ ropp.b[0]) | (s.opp.b[1] ^ ropp.b[1]) | (s.opp.b[2] ^ ropp.b[2]) | (s.opp.b[3] ^ ropp.b[3])) >> bar) & 1u) != 0;
+    }
+    expand_phase_core<MODE, NT, STUCK_ROWS, CHAIN>(e, sv, x.valid, x.nd, s, prev_own, prev_opp, x.pl, prefix_hit, out_base, out_total, lp, L,
+                                                   out_stuck, chain, out_all);
 }
 
 // ... with the node handed over in registers by the phase before (doubles turns only: the die is the same at every ply)
@@ -409,8 +455,8 @@ __device__ __forceinline__ void expand_phase_chained(const EnvView &e, const Sta
     NodeState s;
     s.own = n.own; s.opp = n.opp; s.pl = n.pl; s.dA = s.dB = n.die; s.dbl = true; s.len = key_len(n.key);
     const uint32_t no_root[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (only the non-doubles rule reads the root)
-    expand_phase_core<MODE, NT, false, MODE != MODE_LEAF>(e, sv, n.valid, Node{n.game, n.key}, s, n.pown, n.popp, no_root, out_base, out_total,
-                                                          lp, L, nullptr, chain, out_all);
+    expand_phase_core<MODE, NT, false, MODE != MODE_LEAF>(e, sv, n.valid, Node{n.game, n.key}, s, n.pown, n.popp, no_root, n.valid && n.hit, out_base,
+                                                          out_total, lp, L, nullptr, chain, out_all);
 }
 
 // nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole grid,
