@@ -113,6 +113,9 @@ struct StagedView {
     uint4 *u_rows;                        // unique rows
     uint2 *u_info;
     long long cap_rows;
+    long long b_base;                     // > 0: the arena is FOUR of b_base rows each -- by the turn's kind (non-doubles, doubles) and by whether the
+                                          // row's moves hit a blot: arena 2 * doubles + hit, counters T_U, T_UB, T_UB + stride, ... -- and the incremental
+                                          // value net gives every workgroup the same number of tiles of each kind
     uint4 *root_rows;                     // [n] the position every game is in at the start of the step (mover's turn bit)
     float *root_hidden;                   // [n][128] W1 x_root + b1 (incremental evaluator, bg_eval.h)
     unsigned long long *best;             // [n] (ordered value bits << 32) | ~key ; 0 = no candidate
@@ -124,6 +127,9 @@ struct StagedView {
 #ifndef BG_CTR_STRIDE
 #define BG_CTR_STRIDE 16
 #endif
-enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_F2 = 4 * BG_CTR_STRIDE, T_COUNT = 5 * BG_CTR_STRIDE };
+enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_F2 = 4 * BG_CTR_STRIDE, T_UB = 5 * BG_CTR_STRIDE /* arenas 1, 2, 3 */,
+       T_COUNT = 8 * BG_CTR_STRIDE };
+constexpr int N_ARENAS = 4;
+__host__ __device__ __forceinline__ int arena_counter(int k) { return k == 0 ? T_U : T_UB + (k - 1) * BG_CTR_STRIDE; }
 
 }  // namespace bg

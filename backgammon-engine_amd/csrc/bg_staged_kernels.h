@@ -189,6 +189,7 @@ struct ExpandLds {
     uint16_t child[NT * 15];           // successor q of the workgroup: parent << 5 | origin (31: the parent itself)
     uint32_t wave[NT / 64];
     unsigned long long slot;
+    unsigned long long slot2[2];
 };
 // A node handed from one phase to the next IN REGISTERS (expand_all_kernel's doubles workgroups): the lane that built successor q
 // of one phase is the node thread of the next -- no node list, no allocation, no reload of the game's planes, no replay of the key
@@ -208,7 +209,7 @@ template <int MODE, int NT, bool STUCK_ROWS, bool CHAIN>
 __device__ __forceinline__ void expand_phase_core(const EnvView &e, const StagedView &sv, bool valid, const Node nd, const NodeState &s,
                                                   const Side &prev_own, const Side &prev_opp, const uint32_t (&root_pl)[8], bool prefix_hit,
                                                   unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
-                                                  ExpandLds<NT> &L, uint32_t *out_stuck, ChainNode *chain, uint32_t *out_all)
+                                                  ExpandLds<NT> &L, uint32_t *out_stuck, ChainNode *chain, uint32_t *out_all, bool s_kind_dbl = false)
 {
     static_assert(!STUCK_ROWS || MODE == MODE_PLY2, "only the ply-2 phase has stuck nodes of its own");
     static_assert(!CHAIN || MODE != MODE_LEAF, "the leaf stage's successors are rows");
@@ -318,11 +319,11 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
     uint32_t total, totB = 0;
     // (the phase's barriers order LDS only -- barrier_lds(), BG_PHASE_FULL_BARRIERS=1: __syncthreads() everywhere -- except the last
     //  one of a phase whose successors the workgroup's next phase fetches from the list)
-    uint32_t off;
+    uint32_t off, totA = 0;
     if (CLASSES) {                         // one scan for both runs: first-run count in the low half, second-run count in the high half (<= 7 680 each)
         uint32_t tot2;
         const uint32_t off2 = block_scan_256<NW, true, PH_LDS>((cnt - cntB) | (cntB << 16), &tot2, s_wave);
-        const uint32_t totA = tot2 & 0xFFFFu;
+        totA = tot2 & 0xFFFFu;
         total = totA + (tot2 >> 16);
         uint16_t *ca = s_child + (off2 & 0xFFFFu), *cb = s_child + totA + (off2 >> 16);
         const uint32_t tag = threadIdx.x << 5;
@@ -347,15 +348,26 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
     const uint32_t q0 = CHAIN ? (uint32_t)NT : 0u;             // first successor that does
     unsigned long long *topA = MODE == MODE_PLY2 ? &sv.tops[T_D2] : (MODE == MODE_PLY3 ? lp.top : &sv.tops[T_U]);
     const unsigned long long capA = MODE == MODE_PLY2 ? (unsigned long long)sv.cap_d2 : (MODE == MODE_PLY3 ? lp.cap : (unsigned long long)sv.cap_rows);
-    const unsigned long long baseA = block_alloc<false, PH_LDS>(topA, listed, &s_slot);     // the scan just synchronised
-    bool ok = baseA + listed <= capA;
+    // (leaf stage, two arenas: the two runs of the phase are allocated from their own counters, both atomics in flight together)
+    const bool two = CLASSES && sv.b_base > 0;
+    const int ar0 = s_kind_dbl ? 2 : 0;                        // (block-uniform) the phase's pair of arenas: non-doubles turns 0 / 1, doubles 2 / 3
+    unsigned long long baseA, baseB2 = 0;
+    bool ok;
+    if (two) {
+        block_alloc2(&sv.tops[arena_counter(ar0)], totA, &sv.tops[arena_counter(ar0 + 1)], total - totA, L.slot2, baseA, baseB2);
+        ok = baseA + totA <= (unsigned long long)sv.b_base && baseB2 + (total - totA) <= (unsigned long long)sv.b_base;
+    } else {
+        baseA = block_alloc<false, PH_LDS>(topA, listed, &s_slot);     // the scan just synchronised
+        ok = baseA + listed <= capA;
+    }
     if (MODE == MODE_PLY2) {                               // stuck doubles nodes are leaf parents as they are
         const uint32_t offB = block_scan_256<NW, true, PH_LDS>(cntB, &totB, s_wave);
         if (STUCK_ROWS) {
-            const unsigned long long baseB = block_alloc<true, PH_LDS>(&sv.tops[T_U], totB, &s_slot);
-            ok = ok && baseB + totB <= (unsigned long long)sv.cap_rows;
+            const bool four = sv.b_base > 0;                   // (four arenas: these are rows of doubles turns; the class does not matter for so few)
+            const unsigned long long baseB = block_alloc<true, PH_LDS>(&sv.tops[arena_counter(four ? 2 : 0)], totB, &s_slot);
+            ok = ok && baseB + totB <= (unsigned long long)(four ? sv.b_base : sv.cap_rows);
             if (ok && cntB) {                              // the row of the node's own position (what the leaf stage writes for o == 31)
-                const unsigned long long d = baseB + offB;
+                const unsigned long long d = (four ? 2ull * (unsigned long long)sv.b_base : 0ull) + baseB + offB;
                 const uint32_t pk = s_par_key[threadIdx.x];
                 const int pl = (int)(pk >> 31);
                 const int a0 = pl ? 4 : 0, b0 = pl ? 0 : 4;
@@ -403,7 +415,9 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
                 apply_move(a, b, pl, o, die);
                 key = key_child(key, o);
             }
-            const unsigned long long d = baseA + (q - q0);
+            const unsigned long long d = two ? (q >= totA ? (unsigned long long)(ar0 + 1) * sv.b_base + baseB2 + (q - totA)
+                                                           : (unsigned long long)ar0 * sv.b_base + baseA + q)
+                                             : baseA + (q - q0);
             if (MODE == MODE_LEAF) {
                 const Side &s1 = pl ? b : a, &s2 = pl ? a : b;
                 sv.u_rows[2 * d] = make_uint4(s1.b[0] | (pl ? TURN_BIT : 0u), s1.b[1], s1.b[2], s1.b[3]);
@@ -426,7 +440,7 @@ template <int MODE, int NT, bool STUCK_ROWS = false, bool CHAIN = false>
 __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView &sv, const NodeIn &x, int np,
                                              unsigned long long *out_base, uint32_t *out_total, const LeafParents &lp,
                                              ExpandLds<NT> &L, uint32_t *out_stuck = nullptr, ChainNode *chain = nullptr,
-                                             uint32_t *out_all = nullptr)
+                                             uint32_t *out_all = nullptr, bool kind_dbl = false)
 {
     (void)np;
     NodeState s;
@@ -443,7 +457,7 @@ __device__ __forceinline__ void expand_phase(const EnvView &e, const StagedView 
         prefix_hit = ((((s.opp.b[0] ^ ropp.b[0]) | (s.opp.b[1] ^ ropp.b[1]) | (s.opp.b[2] ^ ropp.b[2]) | (s.opp.b[3] ^ ropp.b[3])) >> bar) & 1u) != 0;
     }
     expand_phase_core<MODE, NT, STUCK_ROWS, CHAIN>(e, sv, x.valid, x.nd, s, prev_own, prev_opp, x.pl, prefix_hit, out_base, out_total, lp, L,
-                                                   out_stuck, chain, out_all);
+                                                   out_stuck, chain, out_all, kind_dbl);
 }
 
 // ... with the node handed over in registers by the phase before (doubles turns only: the die is the same at every ply)
@@ -456,7 +470,7 @@ __device__ __forceinline__ void expand_phase_chained(const EnvView &e, const Sta
     s.own = n.own; s.opp = n.opp; s.pl = n.pl; s.dA = s.dB = n.die; s.dbl = true; s.len = key_len(n.key);
     const uint32_t no_root[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (only the non-doubles rule reads the root)
     expand_phase_core<MODE, NT, false, MODE != MODE_LEAF>(e, sv, n.valid, Node{n.game, n.key}, s, n.pown, n.popp, no_root, n.valid && n.hit, out_base,
-                                                          out_total, lp, L, nullptr, chain, out_all);
+                                                          out_total, lp, L, nullptr, chain, out_all, true);
 }
 
 // nodes per block iteration: a launch with few nodes (the doubles plies, small envs) spreads them over the whole grid,
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
                 uint32_t total4;
                 NodeIn x4;
                 node_fetch(e, sv.f2, threadIdx.x < n4 ? (long long)(base + c4 + threadIdx.x) : -1ll, x4);
-                expand_phase<MODE_LEAF, NT>(e, sv, x4, NT, &base4, &total4, lp, L);
+                expand_phase<MODE_LEAF, NT>(e, sv, x4, NT, &base4, &total4, lp, L, nullptr, nullptr, nullptr, true);
                 staged_total += total4;
             }
         };

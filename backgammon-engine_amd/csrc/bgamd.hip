@@ -437,12 +437,26 @@ __global__ void rows_read_kernel(const uint4 *__restrict__ rows, const uint32_t 
     }
 }
 
+// (b_base > 0: four arenas -- the logical rows are the rows of arena 0, then those of arena 1, ...; tops = the step's counters)
 __global__ void rows_values_kernel(const uint4 *__restrict__ rows, const float *__restrict__ values, long long first, long long n,
-                                   int32_t *__restrict__ st, float *__restrict__ val)
+                                   int32_t *__restrict__ st, float *__restrict__ val, const unsigned long long *__restrict__ tops, long long b_base)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long r = first + i;
+    long long r = first + i;
+#ifdef BG_EVAL_WGCLOCK                                         // (diagnostic build, tools/eval_wg_clock.py: physical rows)
+    b_base = 0;
+#endif
+    if (b_base > 0) {
+        long long k = 0, rest = r;
+        for (; k < N_ARENAS - 1; ++k) {
+            long long c = (long long)tops[arena_counter((int)k)];
+            if (c > b_base) c = b_base;
+            if (rest < c) break;
+            rest -= c;
+        }
+        r = k * b_base + rest;
+    }
     if (st) {
         const uint4 u0 = rows[2 * r], u1 = rows[2 * r + 1];
         const uint32_t p[8] = {u0.x & ~TURN_BIT, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
@@ -670,6 +684,7 @@ struct bgamd_env {
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
     int choice[4] = {0, 0, 0, 0};           // kernels of the last greedy step (bgamd_env_kernel_choice)
+    bool split_arena = true;               // the greedy step (incremental value net) keeps hit-free rows and the others in two arenas (BGAMD_SPLIT_ARENA=0: one)
     bool expand_merged = true;             // doubles plies + leaf stage in one launch (expand_all_kernel); BGAMD_EXPAND_MERGED=0: two launches
     int expand_parts = 3;                  // timing experiments (BGAMD_EXPAND_PARTS): 1 = only the doubles turns are expanded, 2 = only the others
     int expand_dbl_npb = 128;              // ply-1 nodes a doubles workgroup takes per iteration (BGAMD_EXPAND_DBL_NPB: 64 .. 512)
@@ -822,6 +837,8 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         env->expand_merged = xm ? atoi(xm) != 0 : true;
         const char *xp = getenv("BGAMD_EXPAND_DBL_PCT");
         if (xp && atoi(xp) >= 5 && atoi(xp) <= 95) env->expand_dbl_pct = atoi(xp);
+        const char *sa = getenv("BGAMD_SPLIT_ARENA");
+        env->split_arena = sa ? atoi(sa) != 0 : true;
         const char *xq = getenv("BGAMD_EXPAND_PARTS");
         if (xq && atoi(xq) >= 1 && atoi(xq) <= 3) env->expand_parts = atoi(xq);
         const char *xn = getenv("BGAMD_EXPAND_DBL_NPB");
@@ -888,6 +905,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         sv.cap_d2 = ng * 64 < 4096 ? 4096 : ng * 64;
         sv.cap_f = ng * 256 < 16384 ? 16384 : ng * 256;
         sv.cap_rows = cap;
+        sv.b_base = 0;
         HIPCHK(hipMalloc(&sv.d1, (size_t)sv.cap_d1 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.d2, (size_t)sv.cap_d2 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
@@ -1361,6 +1379,11 @@ struct GreedyRun {
         b1 = env->d_w[slot] + N_HID * N_IN; w2 = b1 + N_HID; b2 = w2 + N_HID;
         sv = env->sv;
         sv.tops = env->tops_base;
+        // two row arenas (by class) for the incremental value net; the other value-net kernels read one
+        sv.b_base = (incremental && env->split_arena) ? (env->sv.cap_rows / N_ARENAS) & ~63ll : 0;
+#ifdef BGAMD_EXPERIMENTAL
+        if (env->mfma_delta && env->wm_ok[slot]) sv.b_base = 0;
+#endif
         parity = 0;
         root_ready = false;
         ev = env->v;
@@ -1492,7 +1515,8 @@ struct GreedyRun {
                                (const float4 *)env->d_wt[slot], w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden,
                                env->v.values, (const uint2 *)sv.u_info, sv.best, &env->v.counters[C_KSTEPS],
                                fused ? sv_next.tops : (unsigned long long *)nullptr, (int)T_COUNT, &env->v.counters[C_ERR],
-                               (unsigned long long)ERRF_DELTA);
+                               (unsigned long long)ERRF_DELTA, sv.b_base > 0 ? (const unsigned long long *)&sv.tops[T_UB] : (const unsigned long long *)nullptr,
+                               (long long)sv.b_base);                 // (the counters of arenas 1, 2, 3 follow one another from T_UB)
         } else {
             const int rc = launch_eval(env, slot, precision, &sv.tops[T_U], sv.cap_rows, sv.u_rows, env->v.values, sv.u_info, sv.best, se);
             if (rc) return rc;
@@ -1527,6 +1551,7 @@ struct GreedyRun {
             }
         }
         env->sv.tops = sv.tops;                                // the set whose T_U describes the last evaluated rows
+        env->sv.b_base = sv.b_base;
         if (fused) { parity ^= 1; sv = sv_next; }
         else if (more) {                                       // dense value-net modes: plain per-step sequence
             HIPCHK(hipMemsetAsync(sv.tops, 0, T_COUNT * 8, s));
@@ -1623,13 +1648,22 @@ int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info, int64_t cap, vo
 {
     ENV_GUARD(env);
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long n = 0;
-    HIPCHK(hipMemcpyAsync(&n, &env->sv.tops[T_U], 8, hipMemcpyDeviceToHost, s));
+    const long long bb = env->sv.b_base;                   // four arenas: the rows of the first, then those of the second, ...
+    const int na = bb > 0 ? N_ARENAS : 1;
+    unsigned long long cnt[N_ARENAS] = {0, 0, 0, 0};
+    for (int k = 0; k < na; ++k) HIPCHK(hipMemcpyAsync(&cnt[k], &env->sv.tops[arena_counter(k)], 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if ((long long)n > env->sv.cap_rows) n = (unsigned long long)env->sv.cap_rows;
-    const long long m = (long long)n < cap ? (long long)n : cap;
-    if (d_info && m > 0) HIPCHK(hipMemcpyAsync(d_info, env->sv.u_info, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
-    return (int64_t)n;
+    const long long cap_a = bb > 0 ? bb : env->sv.cap_rows;
+    long long total = 0, done = 0;
+    for (int k = 0; k < na; ++k) {
+        if ((long long)cnt[k] > cap_a) cnt[k] = (unsigned long long)cap_a;
+        total += (long long)cnt[k];
+        const long long m = (long long)cnt[k] < cap - done ? (long long)cnt[k] : cap - done;
+        if (d_info && m > 0)
+            HIPCHK(hipMemcpyAsync((uint2 *)d_info + done, env->sv.u_info + (long long)k * bb, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+        done += m > 0 ? m : 0;
+    }
+    return (int64_t)total;
 }
 
 int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28, float *d_values, void *stream)
@@ -1638,7 +1672,8 @@ int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, in
     HIPCHK(hipSetDevice(env->device));
     if (n_rows == 0 || (!d_states28 && !d_values)) return BGAMD_OK;
     hipLaunchKernelGGL(rows_values_kernel, grid1(n_rows, 128), dim3(128), 0, (hipStream_t)stream, (const uint4 *)env->sv.u_rows,
-                       (const float *)env->v.values, (long long)first, (long long)n_rows, d_states28, d_values);
+                       (const float *)env->v.values, (long long)first, (long long)n_rows, d_states28, d_values,
+                       (const unsigned long long *)env->sv.tops, (long long)env->sv.b_base);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }
@@ -1765,7 +1800,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
                        (const unsigned long long *)nullptr, (long long)n, (unsigned long long *)nullptr, (const float4 *)env->d_wt[slot],
                        w2, b2, (const uint4 *)sv.root_rows, (const float *)sv.root_hidden, d_values, (const uint2 *)sv.u_info, sv.best,
                        (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0, &env->v.counters[C_ERR],
-                       (unsigned long long)ERRF_DELTA);
+                       (unsigned long long)ERRF_DELTA, (const unsigned long long *)nullptr, 0ll);
     HIPCHK(hipGetLastError());
     return BGAMD_OK;
 }

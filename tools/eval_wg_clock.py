@@ -1,0 +1,23 @@
+"""Per-workgroup run times of the value-net kernel (diagnostic build: tools/ab_build.sh wgclock "-DBG_EVAL_WGCLOCK", BGAMD_LIB=.../libbgamd_wgclock.so):
+every workgroup stores, at the top end of the value array, the microseconds between its first and last instruction and the tiles its waves drew.
+Prints their distribution for a few steady-state steps at 65 536 lanes -> how far the slowest workgroup runs behind the mean (the launch ends with it)."""
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, "backgammon-engine_amd")
+import backgammon_env as bg
+from backgammon_env import _capi
+w = np.fromfile("tests/golden/tdgammonNEW100k.f32", dtype=np.float32)
+n = 65536
+cap = n * 512
+env = bg.VecGame(n, device=0, seed=20240603, arena_rows=cap)
+env.load_weights(w)
+env.run_greedy(180)
+G = 256
+for rep in range(5):
+    env.run_greedy(3)
+    val = torch.empty((2 * G,), dtype=torch.float32, device="cuda")
+    _capi.check(env._lib.bgamd_env_unique_rows_read(env._h, cap - 2 * G, 2 * G, None, C.c_void_p(val.data_ptr()), None), "read")
+    torch.cuda.synchronize()
+    v = val.cpu().numpy()
+    us, tiles = v[G:][::-1], v[:G][::-1]
+    print("step %d: workgroup run time us: min %.1f mean %.1f max %.1f (max - mean %.1f, sigma %.2f); tiles drawn per workgroup: min %d mean %.1f max %d; corr(time, tiles) %.2f"
+          % (rep, us.min(), us.mean(), us.max(), us.max() - us.mean(), us.std(), tiles.min(), tiles.mean(), tiles.max(), np.corrcoef(us, tiles)[0, 1]), flush=True)
