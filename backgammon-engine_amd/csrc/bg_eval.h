@@ -432,15 +432,23 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         na1 = c1 < b_base ? c1 : b_base; na2 = c2 < b_base ? c2 : b_base; na3 = c3 < b_base ? c3 : b_base;
     }
     if (rows_eval_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rows_eval_counter, (unsigned long long)(n_rows + na1 + na2 + na3));
-    const long long t1 = (n_rows + 63) >> 6, t2 = t1 + ((na1 + 63) >> 6), t3 = t2 + ((na2 + 63) >> 6);
-    const long long n_tiles = t3 + ((na3 + 63) >> 6);
+    // the order in which a workgroup meets the arenas (BG_ARENA_ORDER, four digits: 3210 = arena 3 first)
+#ifndef BG_ARENA_ORDER
+#define BG_ARENA_ORDER 123
+#endif
+    constexpr int AO0 = (BG_ARENA_ORDER / 1000) % 10, AO1 = (BG_ARENA_ORDER / 100) % 10, AO2 = (BG_ARENA_ORDER / 10) % 10, AO3 = BG_ARENA_ORDER % 10;
+    static_assert(((1 << AO0) | (1 << AO1) | (1 << AO2) | (1 << AO3)) == 15, "a permutation of 0123");
+    const long long cnt_of[4] = {n_rows, na1, na2, na3};
+    const long long c0 = cnt_of[AO0], c1 = cnt_of[AO1], c2 = cnt_of[AO2], c3 = cnt_of[AO3];
+    const long long t1 = (c0 + 63) >> 6, t2 = t1 + ((c1 + 63) >> 6), t3 = t2 + ((c2 + 63) >> 6);
+    const long long n_tiles = t3 + ((c3 + 63) >> 6);
     // first row of a tile and the end of the rows of its arena
     auto tile_rows = [&](long long t, long long &end) -> long long {
-        if (t < t1) { end = n_rows; return t * 64; }
-        if (t < t2) { end = b_base + na1; return b_base + (t - t1) * 64; }
-        if (t < t3) { end = 2 * b_base + na2; return 2 * b_base + (t - t2) * 64; }
-        end = 3 * b_base + na3;
-        return 3 * b_base + (t - t3) * 64;
+        if (t < t1) { end = AO0 * b_base + c0; return AO0 * b_base + t * 64; }
+        if (t < t2) { end = AO1 * b_base + c1; return AO1 * b_base + (t - t1) * 64; }
+        if (t < t3) { end = AO2 * b_base + c2; return AO2 * b_base + (t - t2) * 64; }
+        end = AO3 * b_base + c3;
+        return AO3 * b_base + (t - t3) * 64;
     };
     const int lane = threadIdx.x & 63;
     // Row -> lane: 16 CONSECUTIVE rows of a tile sit on the 16 lanes the LDS serves together for a ds_read_b128 (the lane groups

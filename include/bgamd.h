@@ -198,7 +198,9 @@ int bgamd_env_legal_moves(bgamd_env *env, const int32_t *d_player, const int32_t
 int64_t bgamd_env_unique_rows_info(bgamd_env *env, void *d_info /* uint32[cap][2] */, int64_t cap, void *stream);
 /* ... and the rows themselves with the value the net gave each: rows [first, first + n_rows) of that list as int32
  * states [n_rows][28] and float values [n_rows] (either may be NULL).  With BGAMD_F32 these are the outputs of the
- * incremental kernel, row by row -- what the parity tests compare with the reference model. */
+ * incremental kernel, row by row -- what the parity tests compare with the reference model.  (Round 4: the step keeps its rows in four
+ * arenas by kind of turn and by whether the moves hit a blot; both calls list them one arena after the other, i.e. `first` counts rows
+ * of that list.  The order of the rows inside an arena is the order in which the leaf stage's workgroups allocated them: no meaning.) */
 int bgamd_env_unique_rows_read(bgamd_env *env, int64_t first, int64_t n_rows, int32_t *d_states28, float *d_values,
                                void *stream);
 
