@@ -9,7 +9,7 @@ shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0], 
 with open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w") as f:
     f.write([l for l in open(os.path.join(src, "bench_under_rocprof.log")) if l.startswith("{")][-1])
 KEYS = ("roots_kernel", "boundary_kernel", "doubles_kernel", "eval_rows_delta_kernel", "root_hidden_bf16x3_kernel", "root_hidden_resident_kernel", "eval_rows_f32_kernel",
-        "apply_kernel", "eval_rows_f16x2_kernel", "eval_rows_bf16_kernel", "expand_kernel<3")
+        "apply_kernel", "eval_rows_f16x2_kernel", "eval_rows_bf16_kernel", "expand_kernel<3", "expand_all_kernel")
 
 
 def load(d, name):
