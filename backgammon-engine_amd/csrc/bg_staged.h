@@ -110,6 +110,10 @@ struct StagedView {
     long long cap_d1, cap_d2, cap_f;
     Node *f2;                             // leaf parents of the doubles turns when one launch expands everything (expand_all_kernel)
     long long cap_f2;
+    int shards;                           // 1, or LIST_SHARDS: the roots' lists (D1, F) as that many lists of cap / LIST_SHARDS entries with a counter each
+                                          // (workgroup b of the roots appends to lists b % shards; workgroup w of a kind of expand_all_kernel reads
+                                          // lists w % shards): 512 workgroups reach their allocation at the same moment, and atomics on one address
+                                          // are served one after the other
     uint4 *u_rows;                        // unique rows
     uint2 *u_info;
     long long cap_rows;
@@ -128,7 +132,10 @@ struct StagedView {
 #define BG_CTR_STRIDE 16
 #endif
 enum { T_D1 = 0, T_D2 = BG_CTR_STRIDE, T_F = 2 * BG_CTR_STRIDE, T_U = 3 * BG_CTR_STRIDE, T_F2 = 4 * BG_CTR_STRIDE, T_UB = 5 * BG_CTR_STRIDE /* arenas 1, 2, 3 */,
-       T_COUNT = 8 * BG_CTR_STRIDE };
+       T_FS = 8 * BG_CTR_STRIDE /* F lists 1, 2, 3 */, T_DS = 11 * BG_CTR_STRIDE /* D1 lists 1, 2, 3 */, T_COUNT = 14 * BG_CTR_STRIDE };
+constexpr int LIST_SHARDS = 4;
+__host__ __device__ __forceinline__ int f_counter(int k) { return k == 0 ? T_F : T_FS + (k - 1) * BG_CTR_STRIDE; }
+__host__ __device__ __forceinline__ int d1_counter(int k) { return k == 0 ? T_D1 : T_DS + (k - 1) * BG_CTR_STRIDE; }
 constexpr int N_ARENAS = 4;
 __host__ __device__ __forceinline__ int arena_counter(int k) { return k == 0 ? T_U : T_UB + (k - 1) * BG_CTR_STRIDE; }
 

@@ -83,8 +83,13 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
     const uint32_t totF = totFD & 0xFFFFu, totD = totFD >> 16;
     uint32_t offF = offFD & 0xFFFFu, offD = offFD >> 16;
     unsigned long long baseF, baseD;
-    block_alloc2(&sv.tops[T_F], totF, &sv.tops[T_D1], totD, s_slot, baseF, baseD);
-    const bool okF = baseF + totF <= (unsigned long long)sv.cap_f, okD = baseD + totD <= (unsigned long long)sv.cap_d1;
+    // (sharded lists: this workgroup's lists are number blockIdx.x % shards; bases below are absolute positions in sv.f / sv.d1)
+    const int sh = sv.shards > 1 ? (int)(blockIdx.x % (unsigned)sv.shards) : 0;
+    const unsigned long long capF = (unsigned long long)(sv.cap_f / sv.shards), capD = (unsigned long long)(sv.cap_d1 / sv.shards);
+    block_alloc2(&sv.tops[f_counter(sh)], totF, &sv.tops[d1_counter(sh)], totD, s_slot, baseF, baseD);
+    const bool okF = baseF + totF <= capF, okD = baseD + totD <= capD;
+    baseF += (unsigned long long)sh * capF;
+    baseD += (unsigned long long)sh * capD;
     if (!okF || !okD) flag_overflow(e);
     if (c.live) {
         const uint32_t gg = (uint32_t)g;
@@ -571,12 +576,15 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
     // different workgroups, and follow one another inside one.)
     // (parts: timing experiments only -- bit 0: the doubles turns, bit 1: the non-doubles leaf stage; 3 = the whole step)
     const bool do_dbl = blockIdx.x < n_dbl && (parts & 1u), do_leaf = blockIdx.x >= n_dbl && (parts & 2u);
-    const unsigned long long d_first = blockIdx.x, d_stride = n_dbl;
-    const unsigned long long l_first = blockIdx.x - n_dbl, l_stride = gridDim.x - n_dbl;
     if (do_dbl) {
         const LeafParents lp{sv.f2, &sv.tops[T_F2], (unsigned long long)sv.cap_f2};
-        unsigned long long n_in = sv.tops[T_D1];
-        if (n_in > (unsigned long long)sv.cap_d1) n_in = (unsigned long long)sv.cap_d1;
+        // (sharded lists: this workgroup takes list d_first % shards, as the d_first / shards-th of d_stride / shards workgroups)
+        const int shd = sv.shards > 1 ? (int)(blockIdx.x % (unsigned)sv.shards) : 0;
+        const unsigned long long capD = (unsigned long long)(sv.cap_d1 / sv.shards);
+        const Node *d1_list = sv.d1 + (unsigned long long)shd * capD;
+        unsigned long long n_in = sv.tops[d1_counter(shd)];
+        if (n_in > capD) n_in = capD;
+        const unsigned long long d_first = (unsigned long long)blockIdx.x / (unsigned)sv.shards, d_stride = (unsigned long long)n_dbl / (unsigned)sv.shards;
         if (d_first == 0) dnodes = n_in;
         unsigned long long NPB = (n_in + d_stride - 1) / d_stride;
         NPB = NPB < 1 ? 1 : (NPB > (unsigned long long)dbl_npb ? (unsigned long long)dbl_npb : NPB);           // (dbl_npb <= NT)
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
             uint32_t over2, over3, all2, all3, total4, stuck2;
             NodeIn x2;
             ChainNode n3, n4;
-            node_fetch(e, sv.d1, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
+            node_fetch(e, d1_list, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
             expand_phase<MODE_PLY2, NT, true, true>(e, sv, x2, (int)NPB, &over2_base, &over2, lp, L, &stuck2, &n3, &all2);
             dnodes += all2;
             fnodes += stuck2;
@@ -625,8 +633,13 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
         }
     }
     if (do_leaf) {
-        unsigned long long n_in = sv.tops[T_F];
-        if (n_in > (unsigned long long)sv.cap_f) n_in = (unsigned long long)sv.cap_f;
+        const unsigned int lw = blockIdx.x - n_dbl;
+        const int shf = sv.shards > 1 ? (int)(lw % (unsigned)sv.shards) : 0;
+        const unsigned long long capF = (unsigned long long)(sv.cap_f / sv.shards);
+        const Node *f_list = sv.f + (unsigned long long)shf * capF;
+        unsigned long long n_in = sv.tops[f_counter(shf)];
+        if (n_in > capF) n_in = capF;
+        const unsigned long long l_first = lw / (unsigned)sv.shards, l_stride = (unsigned long long)(gridDim.x - n_dbl) / (unsigned)sv.shards;
         if (l_first == 0) fnodes += n_in;
         // a contiguous share per workgroup, cut into equal phases of at most NT parents (645 parents are 2 x 323, not 512 + 133: a phase
         // costs its latencies whatever it holds, and equal shares end together)
@@ -640,9 +653,9 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
             return (c < chunks && threadIdx.x < per && node < hi) ? (long long)node : -1ll;
         };
         NodeIn cur, nxt;
-        node_fetch(e, sv.f, idx_of(0), cur);
+        node_fetch(e, f_list, idx_of(0), cur);
         for (unsigned long long c = 0; c < chunks; ++c) {
-            node_fetch(e, sv.f, idx_of(c + 1), nxt);
+            node_fetch(e, f_list, idx_of(c + 1), nxt);
             unsigned long long base;
             uint32_t total;
             expand_phase<MODE_LEAF, NT>(e, sv, cur, (int)per, &base, &total, leaf_parents_shared(sv), L);

@@ -684,6 +684,7 @@ struct bgamd_env {
     void *d_tmp = nullptr;                 // ... and of its enumerate call (states | seq | len), grown on demand
     size_t tmp_bytes = 0;
     int choice[4] = {0, 0, 0, 0};           // kernels of the last greedy step (bgamd_env_kernel_choice)
+    bool list_shards = true;               // the roots' node lists in LIST_SHARDS parts (BGAMD_LIST_SHARDS=0: one list each)
     bool split_arena = true;               // the greedy step (incremental value net) keeps hit-free rows and the others in two arenas (BGAMD_SPLIT_ARENA=0: one)
     bool expand_merged = true;             // doubles plies + leaf stage in one launch (expand_all_kernel); BGAMD_EXPAND_MERGED=0: two launches
     int expand_parts = 3;                  // timing experiments (BGAMD_EXPAND_PARTS): 1 = only the doubles turns are expanded, 2 = only the others
@@ -837,6 +838,8 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         env->expand_merged = xm ? atoi(xm) != 0 : true;
         const char *xp = getenv("BGAMD_EXPAND_DBL_PCT");
         if (xp && atoi(xp) >= 5 && atoi(xp) <= 95) env->expand_dbl_pct = atoi(xp);
+        const char *ls = getenv("BGAMD_LIST_SHARDS");
+        env->list_shards = ls ? atoi(ls) != 0 : true;
         const char *sa = getenv("BGAMD_SPLIT_ARENA");
         env->split_arena = sa ? atoi(sa) != 0 : true;
         const char *xq = getenv("BGAMD_EXPAND_PARTS");
@@ -906,6 +909,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         sv.cap_f = ng * 256 < 16384 ? 16384 : ng * 256;
         sv.cap_rows = cap;
         sv.b_base = 0;
+        sv.shards = 1;
         HIPCHK(hipMalloc(&sv.d1, (size_t)sv.cap_d1 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.d2, (size_t)sv.cap_d2 * sizeof(Node)));
         HIPCHK(hipMalloc(&sv.f, (size_t)sv.cap_f * sizeof(Node)));
@@ -1363,6 +1367,7 @@ struct GreedyRun {
     int flags, slot, precision, parity = 0;
     float epsilon;
     bool incremental;
+    long long xall_nd = 1, xall_nl = 1;    // expand_all_kernel: workgroups for the doubles turns / for the non-doubles leaf stage
     StagedView sv;
     EnvView ev;                            // the env's view as this run's launches take it (ring log: the slots of the step at hand)
     long long cur_step = 0;                // ring log: the env step being played
@@ -1381,6 +1386,18 @@ struct GreedyRun {
         sv.tops = env->tops_base;
         // two row arenas (by class) for the incremental value net; the other value-net kernels read one
         sv.b_base = (incremental && env->split_arena) ? (env->sv.cap_rows / N_ARENAS) & ~63ll : 0;
+        {   // grid of expand_all_kernel: two 512-thread workgroups per CU are resident, the first xall_nd take the doubles turns (one of each kind
+            // per CU at the default share); the roots' lists in LIST_SHARDS parts when both counts divide
+            const long long n = env->v.n, slots = 2ll * env->n_cu;
+            long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
+            const long long nd_lim = slots * env->expand_dbl_pct / 100;
+            nd = nd < 1 ? 1 : (nd > nd_lim ? nd_lim : nd);
+            long long nl = (n * 16 + XALL_NT - 1) / XALL_NT;
+            const long long nl_lim = slots - nd_lim < 1 ? 1 : slots - nd_lim;
+            nl = nl < 1 ? 1 : (nl > nl_lim ? nl_lim : nl);
+            xall_nd = nd; xall_nl = nl;
+            sv.shards = (env->expand_merged && env->list_shards && nd % LIST_SHARDS == 0 && nl % LIST_SHARDS == 0) ? LIST_SHARDS : 1;
+        }
 #ifdef BGAMD_EXPERIMENTAL
         if (env->mfma_delta && env->wm_ok[slot]) sv.b_base = 0;
 #endif
@@ -1470,14 +1487,7 @@ struct GreedyRun {
             // one launch: the doubles turns' plies 2, 3 and leaf stage on the first workgroups, the non-doubles leaf stage on the others
             // (two 512-thread workgroups per CU are resident: one of each kind per CU at the default share)
             KTimer t(env, s, 5);
-            const long long slots = 2ll * ss.n_cu;
-            long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
-            const long long nd_lim = slots * env->expand_dbl_pct / 100;
-            nd = nd < 1 ? 1 : (nd > nd_lim ? nd_lim : nd);
-            long long nl = (n * 16 + XALL_NT - 1) / XALL_NT;
-            const long long nl_lim = slots - nd_lim < 1 ? 1 : slots - nd_lim;
-            nl = nl < 1 ? 1 : (nl > nl_lim ? nl_lim : nl);
-            const long long grid = nd + nl;
+            const long long nd = xall_nd, grid = xall_nd + xall_nl;
             hipLaunchKernelGGL(expand_all_kernel, dim3((unsigned)grid), dim3(XALL_NT), 0, s, ev, sv, (unsigned)nd,
                                (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts);
         } else {
