@@ -570,6 +570,9 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
 {
     constexpr int NT = XALL_NT;
     __shared__ ExpandLds<NT> L;
+#ifdef BG_EVAL_WGCLOCK
+    const unsigned long long xall_t0 = wall_clock64();
+#endif
     unsigned long long staged_total = 0, fnodes = 0, dnodes = 0;
     // the first n_dbl workgroups take the doubles turns, the others the non-doubles leaf stage.  (Every workgroup taking a share of both
     // kinds -- the same mix everywhere -- was measured too: 32-37 us against 29.4: the two kinds overlap when they share a CU as
@@ -600,6 +603,9 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
                 staged_total += total4;
             }
         };
+        // (a workgroup takes a CONTIGUOUS run of the list: every W-th node instead -- a game's ply-1 nodes on different workgroups, whose
+        // rows then vary less than the 600 ... 3 200 of today -- was measured: expansion 29.1 -> 30.7 us, and the value net 74.5 -> 76.0 us
+        // because a game's rows then lie all over the arenas)
         for (unsigned long long blk = d_first; blk * NPB < n_in; blk += d_stride) {
             const unsigned long long first = blk * NPB;
             const unsigned long long cnt = n_in - first < NPB ? n_in - first : NPB;
@@ -667,6 +673,10 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
         if (staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
         if (fnodes) atomicAdd(&e.counters[C_FNODES], fnodes);
         if (dnodes) atomicAdd(&e.counters[C_DNODES], dnodes);
+#ifdef BG_EVAL_WGCLOCK                                         // diagnostic build (tools/eval_wg_clock.py): when each workgroup ended, us after it started, and its rows
+        e.values[e.cap - 1 - 1024 - (long long)blockIdx.x] = (float)(wall_clock64() - xall_t0) * 0.01f;
+        e.values[e.cap - 1 - 2048 - (long long)blockIdx.x] = (float)staged_total;
+#endif
     }
 }
 

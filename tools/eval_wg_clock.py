@@ -19,5 +19,14 @@ for rep in range(5):
     torch.cuda.synchronize()
     v = val.cpu().numpy()
     us, tiles = v[G:][::-1], v[:G][::-1]
+    xv = torch.empty((3072,), dtype=torch.float32, device="cuda")
+    _capi.check(env._lib.bgamd_env_unique_rows_read(env._h, cap - 3072, 3072, None, C.c_void_p(xv.data_ptr()), None), "read")
+    torch.cuda.synchronize()
+    x = xv.cpu().numpy()[::-1]                          # x[k] = values[cap - 1 - k]
+    xt, xr = x[1024:1536], x[2048:2560]                 # expand_all_kernel: run time and rows of workgroup 0 .. 511 (the first 256: doubles turns)
+    for name, sl in (("doubles workgroups", slice(0, 256)), ("non-doubles workgroups", slice(256, 512))):
+        t, r = xt[sl], xr[sl]
+        print("   expand_all %s: run time us min %.1f mean %.1f max %.1f sigma %.2f; rows per workgroup min %d mean %.0f max %d; corr(time, rows) %.2f"
+              % (name, t.min(), t.mean(), t.max(), t.std(), r.min(), r.mean(), r.max(), np.corrcoef(t, r)[0, 1]), flush=True)
     print("step %d: workgroup run time us: min %.1f mean %.1f max %.1f (max - mean %.1f, sigma %.2f); tiles drawn per workgroup: min %d mean %.1f max %d; corr(time, tiles) %.2f"
           % (rep, us.min(), us.mean(), us.max(), us.max() - us.mean(), us.std(), tiles.min(), tiles.mean(), tiles.max(), np.corrcoef(us, tiles)[0, 1]), flush=True)
