@@ -9,6 +9,50 @@ namespace bg {
 
 constexpr int D16_XBUF_U4 = K16_STEPS * 64;             // uint4 per tile: [13 K-steps][64 lanes]
 
+// The root pass's arithmetic (round 4): W1 as f16 hi + f16 lo (22 mantissa bits; relayout_w1_f16x2_root), the features exact in f16
+// (thermometer bits, halves, checker counts with the 1/15 folded into the weights), products exact, fp32 accumulation on
+// v_mfma_f32_32x32x16_f16: TWO MFMAs per (K-step, tile) where the bf16 hi + mid + lo split (rounds 1-4, -DBG_ROOT_F16X2=0) takes three --
+// the pass is MFMA-bound inside the boundary launch (2 waves per SIMD x 312 MFMAs).  Row-level values against the reference model:
+// tests/test_gpu_round2.py::test_delta_kernel_rows_vs_reference_values, test_gpu_round3.py::test_bar_positions_rows_vs_reference_values.
+#ifndef BG_ROOT_F16X2
+#define BG_ROOT_F16X2 1
+#endif
+#if BG_ROOT_F16X2
+constexpr int ROOT_PLANES = 2;
+typedef f16x8 root_vec8;
+#define BG_ROOT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+__device__ __forceinline__ uint32_t root_half_bits(float x) { return (uint32_t)f16_bits((_Float16)x); }
+constexpr uint32_t ROOT_ONE = 0x3C00u;
+#else
+constexpr int ROOT_PLANES = 3;
+typedef bf16x8 root_vec8;
+#define BG_ROOT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+__device__ __forceinline__ uint32_t root_half_bits(float x) { return (uint32_t)f32_to_bf16_rne(x); }
+constexpr uint32_t ROOT_ONE = 0x3F80u;
+#endif
+// the plane set and the count LUT the root pass takes: (f16 hi | lo, f16 LUT) or (bf16 hi | mid | lo, bf16 LUT)
+constexpr bool ROOT_F16X2 = BG_ROOT_F16X2 != 0;
+
+// W1 for the f16 x 2 root pass: the bf16 x 3 layout's positions (relayout_w1_bf16x3), two planes
+inline void relayout_w1_f16x2_root(const float *w1, uint16_t *wl)
+{
+    static const int tail_map[8] = {192, 193, 194, 195, 196, 197, -1, -1};
+    for (int s = 0; s < K16_STEPS; ++s)
+        for (int c = 0; c < 4; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    int f = 16 * s + 8 * (l >> 5) + j;
+                    if (s == 12) f = (l >> 5) == 0 ? tail_map[j] : -1;
+                    float w = f >= 0 && f < N_IN ? w1[(32 * c + (l & 31)) * N_IN + f] : 0.0f;
+                    if (f >= 196) w = w / 15.0f;
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)(w - (float)hi);
+                    const size_t o = (((size_t)s * 4 + c) * 64 + l) * 8 + j;
+                    wl[o] = f16_bits(hi);
+                    wl[(size_t)ROOT3_PART_U4 * 8 + o] = f16_bits(lo);
+                }
+}
+
 // ================================ the root pass with the weights resident in registers =====================================
 // root_hidden_bf16x3_kernel (bg_eval.h, rounds 1-2; experimental build only now) stages the three bf16 planes of W1 (160 KB) through LDS in two K phases per workgroup
 // and needs 21 us for 4 us worth of MFMAs.  Same product, same MFMA sequence per accumulator (K-step ascending, planes hi, mid,
@@ -30,10 +74,10 @@ __global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
     const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
     const long long n_tiles = (n_rows + 31) >> 5;
-    union WF { uint4 u; bf16x8 v; };
-    WF wf[3][K16_STEPS];
+    union WF { uint4 u; root_vec8 v; };
+    WF wf[ROOT_PLANES][K16_STEPS];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < ROOT_PLANES; ++p)
 #pragma unroll
         for (int s = 0; s < K16_STEPS; ++s) wf[p][s].u = wl3[(size_t)p * ROOT3_PART_U4 + ((size_t)s * 4 + c) * 64 + lane];
     constexpr float NL2E = -1.44269504088896340736f;
@@ -63,9 +107,9 @@ __global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
         }
         if (c == 0) {
             const int turn = (p[0] & TURN_BIT) ? 1 : 0;
-            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
-            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
-            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            const uint32_t t0 = (turn == 0 && row_ok) ? ROOT_ONE : 0u, t1 = (turn == 0 || !row_ok) ? 0u : ROOT_ONE;
+            const uint32_t bar1 = root_half_bits(0.5f * (float)count_at(sa, 0)), bar2 = root_half_bits(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = root_half_bits((float)count_at(sa, 25)), off2 = root_half_bits((float)count_at(sb, 0));
             dst[12 * 64] = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
         }
     };
@@ -90,7 +134,7 @@ __global__ __launch_bounds__(ROOTR_THREADS, 2) void root_hidden_resident_kernel(
             WF x;
             x.u = xp[s * 64];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.v, wf[p][s].v, acc, 0, 0, 0);
+            for (int p = 0; p < ROOT_PLANES; ++p) acc = BG_ROOT_MFMA(x.v, wf[p][s].v, acc);
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -126,14 +170,14 @@ constexpr int BROOT_TILES = BROOT_GPW / 32;
 // 39 dependent MFMAs, stores, barrier) on one wave per SIMD) where the MFMAs are 4.8
 constexpr int BROOT_LDS_BYTES = BROOT_TILES * D16_XBUF_U4 * 16 + EVAL16_LUT_BYTES + BROOT_GPW * 32;
 
-struct BRootWeights { uint4 w[3][K16_STEPS]; };              // wave c's three bf16 planes of hidden units 32 c .. 32 c + 31: 156 registers
+struct BRootWeights { uint4 w[ROOT_PLANES][K16_STEPS]; };    // wave c's planes of hidden units 32 c .. 32 c + 31: 104 registers (f16 x 2; bf16 x 3: 156)
 
 // requested BEFORE the roots half of the launch (they do not depend on it): in flight while the roots scan and allocate
 __device__ __forceinline__ void broot_load_weights(const uint4 *__restrict__ wl3, BRootWeights &wf)
 {
     const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < ROOT_PLANES; ++p)
 #pragma unroll
 #if defined(BG_ABL_STEP) && (BG_ABL_STEP & 8)
         for (int s = 0; s < K16_STEPS; ++s) wf.w[p][s] = make_uint4(lane + s, p, c, 0u);
@@ -180,14 +224,14 @@ __device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4
         }
         if (c == 0) {
             const int turn = (p[0] & TURN_BIT) ? 1 : 0;
-            const uint32_t t0 = (turn == 0 && row_ok) ? 0x3F80u : 0u, t1 = (turn == 0 || !row_ok) ? 0u : 0x3F80u;
-            const uint32_t bar1 = f32_to_bf16_rne(0.5f * (float)count_at(sa, 0)), bar2 = f32_to_bf16_rne(0.5f * (float)count_at(sb, 25));
-            const uint32_t off1 = f32_to_bf16_rne((float)count_at(sa, 25)), off2 = f32_to_bf16_rne((float)count_at(sb, 0));
+            const uint32_t t0 = (turn == 0 && row_ok) ? ROOT_ONE : 0u, t1 = (turn == 0 || !row_ok) ? 0u : ROOT_ONE;
+            const uint32_t bar1 = root_half_bits(0.5f * (float)count_at(sa, 0)), bar2 = root_half_bits(0.5f * (float)count_at(sb, 25));
+            const uint32_t off1 = root_half_bits((float)count_at(sa, 25)), off2 = root_half_bits((float)count_at(sb, 0));
             dst[12 * 64] = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
         }
     }
     __syncthreads();
-    union WF { uint4 u; bf16x8 v; };
+    union WF { uint4 u; root_vec8 v; };
     // two tiles per iteration: two independent accumulator chains and twice the LDS reads in flight -- with ONE wave per SIMD nothing else
     // covers an MFMA chain's and an LDS read's latency (a tile at a time: 2.1 us per tile and wave against 1.25 in the stand-alone kernel,
     // whose two workgroups per CU cover each other).  Per accumulator the sequence is unchanged: K-step ascending, planes hi, mid, lo.
@@ -204,11 +248,11 @@ __device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4
             x0.u = xp0[s * 64];
             x1.u = xp1[s * 64];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < ROOT_PLANES; ++p) {
                 WF wv;
                 wv.u = wf.w[p][s];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0.v, wv.v, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1.v, wv.v, acc1, 0, 0, 0);
+                acc0 = BG_ROOT_MFMA(x0.v, wv.v, acc0);
+                acc1 = BG_ROOT_MFMA(x1.v, wv.v, acc1);
             }
         }
 #pragma unroll

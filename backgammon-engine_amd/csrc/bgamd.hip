@@ -662,7 +662,8 @@ struct bgamd_env {
     uint4 *d_wm[2] = {nullptr, nullptr};   // W1^T as f16 hi | lo dwords [198][4][32] for the MFMA delta kernel (bg_eval_mfma.h)
     bool wm_ok[2] = {false, false};        // the slot's table fits f16 (else the VALU delta kernel evaluates that slot)
     bool mfma_delta = false;               // BGAMD_MFMA_DELTA=1: eval_rows_mdelta_kernel instead of eval_rows_delta_kernel
-    uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term)
+    uint4 *d_wl3[2] = {nullptr, nullptr};  // bf16 hi | mid | lo split, bf16 MFMA layout x 3 (root term, rounds 1-4; -DBG_ROOT_F16X2=0)
+    uint4 *d_wr2[2] = {nullptr, nullptr};  // f16 hi | lo split in the same layout (the root pass, bg_root_resident.h)
     uint4 *d_wl16[2] = {nullptr, nullptr}; // bf16 MFMA layout [13][4][64] x 8 bf16
     uint4 *d_wlx2[2] = {nullptr, nullptr}; // f16 hi | lo split, same layout twice
     uint4 *d_wd16[2] = {nullptr, nullptr}; // the same split with -log2(e) and b1 folded in: the register-resident dense kernel (bg_eval_dense16.h)
@@ -891,6 +892,7 @@ static int env_allocate(bgamd_env *env, int64_t n_games, uint64_t seed, uint64_t
         HIPCHK(hipMalloc(&env->d_wm[k], MD_W_BYTES));
 #endif
         HIPCHK(hipMalloc(&env->d_wl3[k], 3 * EVAL16_W_BYTES));
+        HIPCHK(hipMalloc(&env->d_wr2[k], 2 * EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wl16[k], EVAL16_W_BYTES));
         HIPCHK(hipMalloc(&env->d_wlx2[k], EVAL16X2_W_BYTES));
 #ifdef BGAMD_EXPERIMENTAL
@@ -955,7 +957,7 @@ int bgamd_env_destroy(bgamd_env *env)
     hipDeviceSynchronize();
     EnvView &v = env->v;
     void *ptrs[] = {v.planes, v.meta, v.ply, v.episode, v.flags, v.cand_off, v.cand_cnt, v.chosen, v.chosen_seq,
-                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_wd16[0], env->d_wd16[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->sv.root_rows, env->sv.root_hidden,
+                    v.chosen_val, v.rows, v.seqs, v.values, v.counters, env->d_w[0], env->d_wl[0], env->d_wl16[0], env->d_w[1], env->d_wl[1], env->d_wl16[1], env->d_lut, env->d_wlx2[0], env->d_wlx2[1], env->d_wd16[0], env->d_wd16[1], env->d_lut16, env->d_wt[0], env->d_wt[1], env->d_wm[0], env->d_wm[1], env->d_wl3[0], env->d_wl3[1], env->d_wr2[0], env->d_wr2[1], env->sv.root_rows, env->sv.root_hidden,
                     env->sv.d1, env->sv.d2, env->sv.f, env->sv.f2, env->sv.u_rows, env->sv.u_info, env->sv.best, env->tops_base, env->rv.tasks, env->rv.top, env->rv.task_count, env->rv.task_off, env->rv.task_n};
     for (void *p : ptrs) if (p) hipFree(p);
     if (env->d_scalar) hipFree(env->d_scalar);
@@ -1283,6 +1285,8 @@ int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights
     std::vector<uint16_t> wl3((size_t)3 * K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16x3(h_weights, wl3.data());
     HIPCHK(hipMemcpy(env->d_wl3[slot], wl3.data(), 3 * EVAL16_W_BYTES, hipMemcpyHostToDevice));
+    relayout_w1_f16x2_root(h_weights, wl3.data());
+    HIPCHK(hipMemcpy(env->d_wr2[slot], wl3.data(), 2 * EVAL16_W_BYTES, hipMemcpyHostToDevice));
     std::vector<uint16_t> wl16((size_t)K16_STEPS * 4 * 64 * 8);
     relayout_w1_bf16(h_weights, wl16.data());
     uint32_t lut[32];
@@ -1477,8 +1481,8 @@ struct GreedyRun {
                     long long blocks = (n + 31) / 32;
                     if (blocks > 2ll * ss.n_cu) blocks = 2ll * ss.n_cu;                 // two 4-wave workgroups per CU (256 VGPRs each wave)
                     hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS),
-                                       ROOTR_LDS_BYTES, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)env->d_wl3[slot],
-                                       (const uint2 *)env->d_lut, b1, sv.root_hidden);
+                                       ROOTR_LDS_BYTES, s2, (const uint4 *)sv.root_rows, n, (const uint4 *)(ROOT_F16X2 ? env->d_wr2[slot] : env->d_wl3[slot]),
+                                       (const uint2 *)(ROOT_F16X2 ? env->d_lut16 : env->d_lut), b1, sv.root_hidden);
                 }
             }
             if (s2 != s) HIPCHK(hipEventRecord(env->ev_join, s2));
@@ -1551,7 +1555,7 @@ struct GreedyRun {
 #endif
                 if (root_ready)
                     hipLaunchKernelGGL(boundary_kernel<true>, grid1(n, BROOT_GPW), dim3(LANE_NT), BROOT_LDS_BYTES, s, ev, sv, sv_next, xv, flags, epsilon,
-                                       (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1);
+                                       (const uint4 *)(ROOT_F16X2 ? env->d_wr2[slot] : env->d_wl3[slot]), (const uint2 *)(ROOT_F16X2 ? env->d_lut16 : env->d_lut), b1);
                 else
                     hipLaunchKernelGGL(boundary_kernel<false>, grid1(n, LANE_NT), dim3(LANE_NT), 0, s, ev, sv, sv_next, xv, flags, epsilon,
                                        (const uint4 *)nullptr, (const uint2 *)nullptr, (const float *)nullptr);
@@ -1791,7 +1795,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
         long long blocks = (n_roots + 31) / 32;
         if (blocks > 2ll * env->n_cu) blocks = 2ll * env->n_cu;
         hipLaunchKernelGGL(root_hidden_resident_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(ROOTR_THREADS), ROOTR_LDS_BYTES, s,
-                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)env->d_wl3[slot], (const uint2 *)env->d_lut, b1,
+                           (const uint4 *)sv.root_rows, (long long)n_roots, (const uint4 *)(ROOT_F16X2 ? env->d_wr2[slot] : env->d_wl3[slot]), (const uint2 *)(ROOT_F16X2 ? env->d_lut16 : env->d_lut), b1,
                            sv.root_hidden);
     }
     long long dblocks = (n + DELTA_THREADS - 1) / DELTA_THREADS;

@@ -105,9 +105,10 @@ def test_mfma_delta_values_do_not_depend_on_the_piece(bg, weights, monkeypatch):
 
 
 def test_resident_and_lds_staged_root_pass_are_bit_identical(bg, weights, monkeypatch):
-    """The root pass of the incremental value net exists twice: with the three bf16 planes of a wave's 32 hidden units resident in
-    registers (the default since round 3) and staged through LDS in two K phases (BGAMD_ROOT_RESIDENT=0, rounds 1-2).  Same MFMA
-    sequence per accumulator: the same games to the last bit, and the same per-row values through evaluate_incremental."""
+    """The root pass of the incremental value net exists twice: with a wave's weight planes resident in registers (the default since
+    round 3; since round 4 W1 as f16 hi + lo, two MFMAs per K-step) and staged through LDS in two K phases as bf16 hi + mid + lo
+    (BGAMD_ROOT_RESIDENT=0, rounds 1-2).  Until the default took the f16 planes the two were the same bits; now they are two roundings of
+    the same product: the chosen values within 1e-6 of each other from identical positions, and the same move on > 99.9 % of the lanes over 40 steps."""
     n = 8192
     monkeypatch.delenv("BGAMD_ROOT_RESIDENT", raising=False)
     a = bg.VecGame(n, seed=4711)
@@ -115,12 +116,19 @@ def test_resident_and_lds_staged_root_pass_are_bit_identical(bg, weights, monkey
     b = bg.VecGame(n, seed=4711)
     monkeypatch.delenv("BGAMD_ROOT_RESIDENT", raising=False)
     a.load_weights(weights); b.load_weights(weights)
-    for k in (1, 7, 40):
-        a.run_greedy(k, epsilon=0.05); b.run_greedy(k, epsilon=0.05)
-        assert torch.equal(a.states(), b.states()) and torch.equal(a.turns(), b.turns()), k
-        la, lb = a.last_choice(), b.last_choice()
-        assert torch.equal(la["value"], lb["value"]) and torch.equal(la["seq"], lb["seq"])
-    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0
+    assert b.kernel_choice()["experimental_build"]
+    a.run_greedy(40); b.run_greedy(40)
+    same = (a.states() == b.states()).all(1) & (a.turns() == b.turns())
+    assert same.float().mean().item() > 0.999
+    idx = torch.nonzero(same).flatten()
+    a.step_greedy(auto_reset=False); b.step_greedy(auto_reset=False)
+    assert b.kernel_choice()["root"] == "root_hidden_bf16x3_kernel" and a.kernel_choice()["root"] == "root_hidden_resident_kernel"
+    la, lb = a.last_choice(), b.last_choice()
+    moved = la["count"][idx] > 0
+    d = (la["value"][idx] - lb["value"][idx]).abs()[moved].max().item()
+    print(f"root pass f16 x 2 (resident) vs bf16 x 3 (LDS-staged): max |chosen value difference| = {d:.2e} on {int(moved.sum())} lanes")
+    assert d < 1e-6
+    assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
 
 
 def test_f16x2_with_resident_weights_equals_the_lds_staged_f16x2_kernel(bg, weights, monkeypatch):

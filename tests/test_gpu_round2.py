@@ -1,5 +1,5 @@
 """Round-2 GPU parity tests (all through the C ABI):
-  * the headline kernels -- root_hidden_bf16x3_kernel + eval_rows_delta_kernel -- compared ROW BY ROW with the reference
+  * the headline kernels -- the root pass (root_hidden_resident_kernel / boundary_kernel<true>) + eval_rows_delta_kernel -- compared ROW BY ROW with the reference
     model's own outputs (fixture G7, written by the unmodified reference) and with the fp64 oracle;
   * the 65 536-lane configuration (second-stream root pass, fused step boundaries) against the oracle on sampled lanes;
   * the per-GPU shares of the training configs: a 65 536-game TD(lambda) round (config 4) and a 32 768-lane round with
@@ -63,7 +63,7 @@ def test_delta_kernel_rows_vs_reference_values(bg, O, golden_dir, weights):
     """Fixture G7: 124 turns of the reference's greedy games, every distinct afterstate with the value the reference
     model's forward pass gave it.  One greedy step in BGAMD_F32 on those turns: the rows handed to the value net are
     EXACTLY the reference's distinct afterstates and EVERY per-row output of eval_rows_delta_kernel (root term from
-    root_hidden_bf16x3_kernel) is within 1e-5 of the reference (fp32 and fp64)."""
+    root_hidden_resident_kernel: W1 as f16 hi + lo since round 4) is within 1e-5 of the reference (fp32 and fp64)."""
     g = np.load(os.path.join(golden_dir, "g7_candidate_values.npz"))
     roots, off = g["roots"], g["off"]
     R = len(roots)
@@ -104,7 +104,7 @@ def test_delta_kernel_rows_vs_reference_values(bg, O, golden_dir, weights):
     big.load_weights(weights)
     v3 = _np(big.evaluate_incremental(g5["states"].astype(np.int32), g5["turn"], g5["states"].astype(np.int32),
                                       np.arange(len(g5["turn"]), dtype=np.int32)))
-    print("root pass alone (bf16 x 3): max |gpu - reference fp32| = %.3g" % np.abs(v3 - g5["v32"]).max())
+    print("root pass alone (root_hidden_resident_kernel): max |gpu - reference fp32| = %.3g" % np.abs(v3 - g5["v32"]).max())
     assert np.abs(v3 - g5["v32"]).max() < 1e-5 and np.abs(v3 - g5["v64"]).max() < 1e-5
 
 
