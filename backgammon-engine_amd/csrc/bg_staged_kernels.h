@@ -566,9 +566,13 @@ __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvV
 #define BG_XALL_NT 512
 #endif
 constexpr int XALL_NT = BG_XALL_NT;
-__global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, StagedView sv, unsigned n_dbl, unsigned dbl_npb, unsigned parts)
+__global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, StagedView sv, unsigned n_dbl, unsigned dbl_npb, unsigned parts,
+                                                                  unsigned long long *__restrict__ zero_words, int n_zero_words)
 {
     constexpr int NT = XALL_NT;
+    // multi-step runs: the OTHER set of list counters is cleared here, while no kernel is using it, for the roots of the next step (which share
+    // a launch with this step's apply)
+    if (zero_words && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < n_zero_words) zero_words[threadIdx.x] = 0ull;
     __shared__ ExpandLds<NT> L;
 #ifdef BG_EVAL_WGCLOCK
     const unsigned long long xall_t0 = wall_clock64();

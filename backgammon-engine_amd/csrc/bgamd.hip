@@ -1487,13 +1487,16 @@ struct GreedyRun {
             }
             if (s2 != s) HIPCHK(hipEventRecord(env->ev_join, s2));
         }
+        StagedView sv_next = sv;
+        sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
         if (env->expand_merged) {
             // one launch: the doubles turns' plies 2, 3 and leaf stage on the first workgroups, the non-doubles leaf stage on the others
             // (two 512-thread workgroups per CU are resident: one of each kind per CU at the default share)
             KTimer t(env, s, 5);
             const long long nd = xall_nd, grid = xall_nd + xall_nl;
             hipLaunchKernelGGL(expand_all_kernel, dim3((unsigned)grid), dim3(XALL_NT), 0, s, ev, sv, (unsigned)nd,
-                               (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts);
+                               (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts, more ? sv_next.tops : (unsigned long long *)nullptr,
+                               (int)T_COUNT);
         } else {
             {
                 KTimer t(env, s, 4);
@@ -1504,9 +1507,9 @@ struct GreedyRun {
                 hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, ev, sv);
             }
         }
-        const bool fused = more && incremental;                // the dense kernels do not clear the other counter set
-        StagedView sv_next = sv;
-        sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
+        // inside a run the apply of this step and the roots of the next share a launch; the counter set those roots allocate from is cleared
+        // earlier in THIS step, while nothing uses it: by the expansion launch (every value-net mode), else by the incremental value net
+        const bool fused = more && (incremental || env->expand_merged);
         hipStream_t se = s;
         if (incremental) {
             if (own_root_launch && ss.root != s) HIPCHK(hipStreamWaitEvent(s, env->ev_join, 0));
@@ -1549,7 +1552,7 @@ struct GreedyRun {
             ev.end_slot = ev.traj_ring ? cur_step % ev.traj_ring : 0;      // the apply half closes the step the last roots began
             if (fused) {
                 next_log_slot();                                           // ... and the roots half begins the next one
-                root_ready = env->root_in_boundary;
+                root_ready = incremental && env->root_in_boundary;
 #ifdef BGAMD_EXPERIMENTAL
                 if (env->root_f32_mfma || !env->root_resident) root_ready = false;          // (the other root passes exist as launches only)
 #endif

@@ -30,7 +30,7 @@ def timeline(d):
             cur = [(s, e, name)]
         elif cur is not None:
             cur.append((s, e, "expand_kernel<LEAF>" if name == "expand_kernel" else name))
-    steps = [st for st in steps if 4 <= len(st) <= 7 and (st[-1][1] - st[0][0]) < 400000][-200:]
+    steps = [st for st in steps if 3 <= len(st) <= 7 and (st[-1][1] - st[0][0]) < 400000][-200:]
     if steps:
         common = max(set(len(st) for st in steps), key=[len(st) for st in steps].count)
         steps = [st for st in steps if len(st) == common]
