@@ -201,4 +201,14 @@ __host__ __device__ __forceinline__ int opening_turn(uint64_t seed, uint64_t gid
     }
 }
 
+// A block barrier that orders LDS traffic only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. every wave
+// first waits for its global stores to be acknowledged (s_waitcnt vmcnt(0)).  Where a barrier only orders LDS records -- the expansion phases between
+// writing rows that nobody in the launch reads back, the learner's forward pass with its prefetches in flight -- this one lets global traffic run on.
+__device__ __forceinline__ void barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace bg

@@ -31,15 +31,6 @@ __host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
 
 struct Node { uint32_t game, key; };
 
-// A block barrier that orders LDS traffic only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. every wave
-// first waits for its global stores to be acknowledged (s_waitcnt vmcnt(0)).  The expansion phases synchronise on LDS records between
-// writing rows that nobody in the launch reads back: with this barrier the stores drain behind the next phase's work.
-__device__ __forceinline__ void barrier_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 template <bool LDS_ONLY>
 __device__ __forceinline__ void block_barrier()
 {
