@@ -8,7 +8,7 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_f32
 shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_kernel_stats_default_bench.csv"))
 with open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w") as f:
     f.write([l for l in open(os.path.join(src, "bench_under_rocprof.log")) if l.startswith("{")][-1])
-KEYS = ("roots_kernel", "boundary_kernel", "doubles_kernel", "eval_rows_delta_kernel", "root_hidden_bf16x3_kernel", "root_hidden_resident_kernel", "eval_rows_f32_kernel",
+KEYS = ("roots_kernel", "boundary_kernel<true>", "boundary_kernel<false>", "doubles_kernel", "eval_rows_delta_kernel", "root_hidden_bf16x3_kernel", "root_hidden_resident_kernel", "eval_rows_f32_kernel",
         "apply_kernel", "eval_rows_f16x2_kernel", "eval_rows_bf16_kernel", "expand_kernel<3", "expand_all_kernel")
 
 
