@@ -80,7 +80,9 @@ int bgamd_device_count(void);
  * Lane g plays game_id = lane_offset + g + episode * lane_stride; dice/choice words are
  * Philox4x32-10(key = seed, counter = (game_id, ply, stream)) so a shard's games do not
  * depend on how many shards there are.  arena_rows = capacity of the candidate arena
- * (0 = default 256 rows per game, min 65 536). */
+ * (0 = default 256 rows per game, min 65 536).  The greedy step with the incremental value net (BGAMD_F32) uses it as four
+ * arenas of arena_rows / 4 (non-doubles / doubles turn x no blot hit / hit): BGAMD_E_ARENA is raised when ONE of them runs
+ * over in a step -- the distinct afterstates of a step average 17 per game over all four, 64 per game and arena are the default. */
 int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed,
                      uint64_t lane_offset, uint64_t lane_stride, int64_t arena_rows);
 int bgamd_env_destroy(bgamd_env *env);
