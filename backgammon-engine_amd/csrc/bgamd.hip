@@ -1392,7 +1392,7 @@ struct GreedyRun {
         sv.b_base = (incremental && env->split_arena) ? (env->sv.cap_rows / N_ARENAS) & ~63ll : 0;
         {   // grid of expand_all_kernel: two 512-thread workgroups per CU are resident, the first xall_nd take the doubles turns (one of each kind
             // per CU at the default share); the roots' lists in LIST_SHARDS parts when both counts divide
-            const long long n = env->v.n, slots = 2ll * env->n_cu;
+            const long long n = env->v.n, slots = (1024 / XALL_NT) * (long long)env->n_cu;       // 16 waves of expand_all_kernel per CU
             long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
             const long long nd_lim = slots * env->expand_dbl_pct / 100;
             nd = nd < 1 ? 1 : (nd > nd_lim ? nd_lim : nd);
