@@ -237,6 +237,14 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
 #else
     constexpr bool CLASSES = MODE == MODE_LEAF;
 #endif
+#ifdef BG_EVAL_WGCLOCK                                         // diagnostic build: thread 0's time in the phase's stages -> the top end of the value array
+    const unsigned long long pt0 = wall_clock64();
+#define BG_PSTAMP(K) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); \
+        e.values[e.cap - 1 - 4096 - (long long)blockIdx.x * 8 - (K)] += (float)(now_ - pt_) * 0.01f; pt_ = now_; } } while (0)
+    unsigned long long pt_ = pt0;
+#else
+#define BG_PSTAMP(K) do { } while (0)
+#endif
     uint32_t cnt = 0, cntB = 0;            // successors of this node; (PLY2) 1 if the node is stuck -> F; (leaf stage) successors of the second run
     uint32_t succ = 0, succ_hit = 0;       // their origins; (leaf stage) those of the second run
     if (valid) {
@@ -321,6 +329,7 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
                 s_par_key[threadIdx.x] = nd.key | (prefix_hit ? 0x01000000u : 0u) | ((uint32_t)die << 27) | (s.pl ? 0x80000000u : 0u);
         }
     }
+    BG_PSTAMP(0);                          // node logic
     uint32_t total, totB = 0;
     // (the phase's barriers order LDS only -- barrier_lds(), BG_PHASE_FULL_BARRIERS=1: __syncthreads() everywhere -- except the last
     //  one of a phase whose successors the workgroup's next phase fetches from the list)
@@ -348,6 +357,7 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
         while (succ) { const int o = __ffs(succ) - 1; succ &= succ - 1; *c++ = (uint16_t)(tag | (uint32_t)o); }
     }
     (void)off;
+    BG_PSTAMP(1);                          // scan + successor table
     // what goes through the output list: everything, or (CHAIN) the successors past the first NT
     const uint32_t listed = CHAIN ? (total > (uint32_t)NT ? total - (uint32_t)NT : 0u) : total;
     const uint32_t q0 = CHAIN ? (uint32_t)NT : 0u;             // first successor that does
@@ -391,6 +401,7 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
     }
     if (!ok) flag_overflow(e);
     block_barrier<PH_LDS>();                               // parent records and offsets are in place
+    BG_PSTAMP(2);                          // allocation(s)
     if (CHAIN) chain->valid = false;
     if (ok) {
         for (uint32_t q = CHAIN ? threadIdx.x : threadIdx.x + q0; q < total; q += NT) {
@@ -435,6 +446,8 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
     // the records are reused by the next phase; where that phase fetches what this one wrote to a list (one ply per phase: not the
     // rows, not the register hand-off) its reads come after a barrier that has waited for the stores
     block_barrier<PH_LDS && (MODE == MODE_LEAF || CHAIN)>();
+    BG_PSTAMP(3);                          // successors built and written
+#undef BG_PSTAMP
     *out_base = baseA;
     *out_total = ok ? listed : 0u;
     if (out_all) *out_all = ok ? total : 0u;
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
     __shared__ ExpandLds<NT> L;
 #ifdef BG_EVAL_WGCLOCK
     const unsigned long long xall_t0 = wall_clock64();
+    if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) e.values[e.cap - 1 - 4096 - (long long)blockIdx.x * 8 - k] = 0.0f;
 #endif
     unsigned long long staged_total = 0, fnodes = 0, dnodes = 0;
     // the first n_dbl workgroups take the doubles turns, the others the non-doubles leaf stage.  (Every workgroup taking a share of both
