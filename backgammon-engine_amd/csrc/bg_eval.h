@@ -496,6 +496,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         const uint4 r0 = nr0, r1 = nr1;
         const f32x4_t *ah = reinterpret_cast<const f32x4_t *>(root_hidden + (long long)inf.x * N_HID);
         const uint32_t p[8] = {nx0.x & ~TURN_BIT, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w};
+        const uint32_t mover = (nx0.x & TURN_BIT) ? 1u : 0u;       // the row carries the turn bit of the side that moved (model.py:209)
         const uint32_t q[8] = {valid ? r0.x & ~TURN_BIT : 0u, valid ? r0.y : 0u, valid ? r0.z : 0u, valid ? r0.w : 0u,
                                valid ? r1.x : 0u, valid ? r1.y : 0u, valid ? r1.z : 0u, valid ? r1.w : 0u};
         {
@@ -520,6 +521,46 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
         if (cnt < DELTA_MAX) lst[cnt * 64] = (uint16_t)((uint32_t)(F) | ((uint32_t)(((TYPE) == 1 ? 1 : 2) * (M)) & 255u) << 8); \
         ++cnt;                                                                                       \
     }
+#if !defined(BG_DECODE_MOVER_FIRST) || BG_DECODE_MOVER_FIRST
+        // The MOVER's side first, then the other one -- which differs from the root only where a blot was hit, i.e. in no lane of a tile of the
+        // hit-free arenas (two thirds of the rows): the second pass is skipped there for the whole wave (one ballot).
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t sd = mover ^ (uint32_t)pass;        // per lane: 0 = PLAYER1's planes, 1 = PLAYER2's
+            const uint32_t b0 = sd ? p[4] : p[0], b1 = sd ? p[5] : p[1], b2 = sd ? p[6] : p[2], b3 = sd ? p[7] : p[3];
+            const uint32_t c0 = sd ? q[4] : q[0], c1 = sd ? q[5] : q[1], c2 = sd ? q[6] : q[2], c3 = sd ? q[7] : q[3];
+            const uint32_t diff = (b0 ^ c0) | (b1 ^ c1) | (b2 ^ c2) | (b3 ^ c3);
+            if (pass == 1 && __ballot(diff != 0u) == 0ull) break;
+            const uint32_t ge_new[3] = {b0 | b1 | b2 | b3, b1 | b2 | b3, (b0 & b1) | b2 | b3};
+            const uint32_t ge_old[3] = {c0 | c1 | c2 | c3, c1 | c2 | c3, (c0 & c1) | c2 | c3};
+            const uint32_t side4 = 4u * sd;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {               // thermometer features n>=1, n>=2, n>=3: ±1 where the bit flips
+                uint32_t x = (ge_new[k] ^ ge_old[k]) & PTS;
+                while (x) {
+                    const int pos = __ffs(x) - 1; x &= x - 1;
+                    BG_PUSH(delta_row_board(pos - 1, 0) + side4 + (uint32_t)k, 0, ((ge_new[k] >> pos) & 1u) ? 1 : -1);
+                }
+            }
+            uint32_t x4 = diff & PTS & ((b2 | b3) | (c2 | c3)); // (n-3)/2 can only move where n >= 4 before or after
+            const Side sn{{b0, b1, b2, b3}}, so{{c0, c1, c2, c3}};
+            while (x4) {
+                const int pos = __ffs(x4) - 1; x4 &= x4 - 1;
+                const int n1 = count_at(sn, pos), n0 = count_at(so, pos);
+                const int d = (n1 > 3 ? n1 - 3 : 0) - (n0 > 3 ? n0 - 3 : 0);
+                if (d) BG_PUSH(delta_row_board(pos - 1, 0) + side4 + 3u, 1, d);
+            }
+            // bar and borne-off counters: PLAYER1 bar = pos 0 (feature 194, x = n/2), off = pos 25 (196, n/15); PLAYER2 bar = pos 25 (195), off = pos 0 (197)
+            if (diff & 1u) {
+                const int d = count_at(sn, 0) - count_at(so, 0);
+                BG_PUSH(sd ? (uint32_t)delta_row(197) : (uint32_t)delta_row(194), 1, sd ? 2 * d : d);
+            }
+            if (diff & (1u << 25)) {
+                const int d = count_at(sn, 25) - count_at(so, 25);
+                BG_PUSH(sd ? (uint32_t)delta_row(195) : (uint32_t)delta_row(196), 1, sd ? d : 2 * d);
+            }
+        }
+#else
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
             const uint32_t b0 = p[4 * sd], b1 = p[4 * sd + 1], b2 = p[4 * sd + 2], b3 = p[4 * sd + 3];
@@ -553,6 +594,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
                 BG_PUSH(delta_row(sd == 0 ? 196 : 195), sd == 0 ? 2 : 1, d);
             }
         }
+#endif
         }
 #undef BG_PUSH
         // A legal turn changes at most 13 features (4 origins + 4 landing points of the mover, 4 hit points + the bar
