@@ -346,6 +346,25 @@ def test_expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, 
     assert a.kernel_choice()["expand"] == "expand_all_kernel" and b.kernel_choice()["expand"] == "doubles_kernel + expand_kernel<LEAF>"
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 1000, 4097, 24576])
+def test_expansion_in_one_launch_odd_env_sizes(bg, weights, monkeypatch, n):
+    """Env sizes around the launch's grid rules (one lane; a wave more or less; workgroup counts that do and do not divide by the four
+    list parts; the size from which the root pass moves into the boundary launch): one launch against two, f32 and bf16, 45 steps with
+    exploration -- the same games and counters."""
+    monkeypatch.delenv("BGAMD_EXPAND_MERGED", raising=False)
+    a = bg.VecGame(n, seed=97 + n)
+    monkeypatch.setenv("BGAMD_EXPAND_MERGED", "0")
+    b = bg.VecGame(n, seed=97 + n)
+    monkeypatch.delenv("BGAMD_EXPAND_MERGED", raising=False)
+    a.load_weights(weights); b.load_weights(weights)
+    for prec in (bg.F32, bg.BF16):
+        for k in (1, 14, 30):
+            a.run_greedy(k, epsilon=0.05, precision=prec); b.run_greedy(k, epsilon=0.05, precision=prec)
+            assert torch.equal(a.states(), b.states()) and torch.equal(a.turns(), b.turns()) and torch.equal(a.dice(), b.dice()), (n, prec, k)
+            assert torch.equal(a.last_choice()["value"], b.last_choice()["value"]), (n, prec, k)
+    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0
+
+
 # ---- the delayed update: a training step in one launch -----------------------------------------------------------------------------
 
 def test_delayed_update_replay_matches_the_delayed_closed_form(bg, weights):
