@@ -690,8 +690,8 @@ struct bgamd_env {
     bool expand_merged = true;             // doubles plies + leaf stage in one launch (expand_all_kernel); BGAMD_EXPAND_MERGED=0: two launches
     int expand_parts = 3;                  // timing experiments (BGAMD_EXPAND_PARTS): 1 = only the doubles turns are expanded, 2 = only the others
     int expand_dbl_npb = 128;              // ply-1 nodes a doubles workgroup takes per iteration (BGAMD_EXPAND_DBL_NPB: 64 .. 512)
-    int expand_dbl_pct = 50;               // share of that launch's workgroups that takes the doubles turns (BGAMD_EXPAND_DBL_PCT: 5 .. 95), the others
-                                           // take the non-doubles leaf stage: one of each kind per CU at 50
+    int expand_dbl_pct = 0;                // share of that launch's workgroups that takes the doubles turns (BGAMD_EXPAND_DBL_PCT: 5 .. 95; 0 = by env
+                                           // size: GreedyRun::init), the others take the non-doubles leaf stage
     bool root_in_boundary = true;          // inside a run the root pass of step t + 1 runs in the boundary launch of step t (bg_root_resident.h);
                                            //   BGAMD_ROOT_IN_BOUNDARY=0: a launch of its own every step, as up to round 3
     bool overlap = true;                   // BGAMD_NO_OVERLAP=1: everything on the caller's stream; BGAMD_OVERLAP=1: second stream for small envs too
@@ -1394,7 +1394,11 @@ struct GreedyRun {
             // per CU at the default share); the roots' lists in LIST_SHARDS parts when both counts divide
             const long long n = env->v.n, slots = (1024 / XALL_NT) * (long long)env->n_cu;       // 16 waves of expand_all_kernel per CU
             long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
-            const long long nd_lim = slots * env->expand_dbl_pct / 100;
+            // the share of workgroups for the doubles turns: BGAMD_EXPAND_DBL_PCT, else by env size -- the doubles chains are what the launch waits
+            // for, and the fewer lanes, the more so (32 768 lanes: 70 % 22.9 us, 50 % 25.1; 65 536: 62 % 28.5, 50 % 29.2; 16 384: 50 % 20.7, 63 % 21.3)
+            const int pct = env->expand_dbl_pct > 0 ? env->expand_dbl_pct : (n >= 49152 ? 62 : (n >= 24576 ? 70 : 50));
+            long long nd_lim = slots * pct / 100;
+            if (nd_lim >= LIST_SHARDS) nd_lim -= nd_lim % LIST_SHARDS;          // (both counts multiples of the list parts: a full launch keeps the lists in parts)
             nd = nd < 1 ? 1 : (nd > nd_lim ? nd_lim : nd);
             long long nl = (n * 16 + XALL_NT - 1) / XALL_NT;
             const long long nl_lim = slots - nd_lim < 1 ? 1 : slots - nd_lim;
