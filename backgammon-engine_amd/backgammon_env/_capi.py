@@ -53,6 +53,7 @@ SYMBOLS = [
     ("bgamd_env_step_random_walk", C.c_int, [_P, C.c_int, _P, _P]),
     ("bgamd_env_load_weights", C.c_int, [_P, _P]),
     ("bgamd_env_load_weights_slot", C.c_int, [_P, C.c_int, _P]),
+    ("bgamd_weights_check", C.c_int, [_P]),
     ("bgamd_env_step_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, _P]),
     ("bgamd_env_run_greedy", C.c_int, [_P, C.c_int, C.c_float, C.c_int, C.c_int64, _P]),
     ("bgamd_env_last_choice", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),

@@ -567,7 +567,8 @@ class ContinuousSelfPlay:
         """The games that ended in the env steps played since the last call -> (game_lane, game_start, lengths, p1_won) device tensors,
         in (end step, lane) order.  A game whose first turns the ring has already overwritten -- longer than ring_steps - window -
         keep_margin (keep_margin: env steps that will be PLAYED while this table is replayed, i.e. the next window of a pipelined
-        loop) -- is dropped and counted in .dropped."""
+        loop) -- is dropped and counted in .dropped.  Call it on the stream play() was issued on: trajectory_step() counts ENQUEUED env
+        steps, and the end records are read by work queued behind them on the current stream."""
         s0, s1 = self._collected, self.env.trajectory_step()
         self._collected = s1
         if s1 - s0 > self.R:

@@ -33,3 +33,18 @@ def aggregate(counters: dict, elapsed_s: float, device=None):
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return {k: int(v) for k, v in zip(keys, c.tolist())}, float(t.item())
+
+
+def census(elapsed_s: float, device=None):
+    """-> (ranks_seen, [elapsed_s of every rank, by rank]): an all-reduced count of ones and an all-gather of the ranks' own timed
+    regions over the bench's process group -- what the line reports as `ranks_seen` / `per_rank_ms_per_step`, so a launch that
+    silently ran fewer ranks than asked for (or one straggling GPU) shows in the record.  (1, [elapsed_s]) when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, [float(elapsed_s)]
+    dev = device if device is not None else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    return int(one.item()), [float(x.item()) for x in every]

@@ -33,10 +33,14 @@ constexpr uint32_t ROOT_ONE = 0x3F80u;
 // the plane set and the count LUT the root pass takes: (f16 hi | lo, f16 LUT) or (bf16 hi | mid | lo, bf16 LUT)
 constexpr bool ROOT_F16X2 = BG_ROOT_F16X2 != 0;
 
-// W1 for the f16 x 2 root pass: the bf16 x 3 layout's positions (relayout_w1_bf16x3), two planes
-inline void relayout_w1_f16x2_root(const float *w1, uint16_t *wl)
+// W1 for the f16 x 2 root pass: the bf16 x 3 layout's positions (relayout_w1_bf16x3), two planes.
+// -> 0, or -1 when a weight does not survive the split: not finite, |w| >= 65 504 (f16 hi would be inf and lo NaN: every value of the
+// slot NaN), or hi + lo further from w than 2^-21 |w| + 2^-24 (the lo plane's quantum).  bgamd_env_load_weights_slot refuses such a
+// table (BGAMD_E_WEIGHTS) instead of playing garbage in the mode advertised as reference parity.
+inline int relayout_w1_f16x2_root(const float *w1, uint16_t *wl)
 {
     static const int tail_map[8] = {192, 193, 194, 195, 196, 197, -1, -1};
+    int rc = 0;
     for (int s = 0; s < K16_STEPS; ++s)
         for (int c = 0; c < 4; ++c)
             for (int l = 0; l < 64; ++l)
@@ -45,12 +49,17 @@ inline void relayout_w1_f16x2_root(const float *w1, uint16_t *wl)
                     if (s == 12) f = (l >> 5) == 0 ? tail_map[j] : -1;
                     float w = f >= 0 && f < N_IN ? w1[(32 * c + (l & 31)) * N_IN + f] : 0.0f;
                     if (f >= 196) w = w / 15.0f;
+                    const float aw = w < 0.0f ? -w : w;
+                    if (!(aw < 65504.0f)) rc = -1;                         // (NaN fails the comparison too)
                     const _Float16 hi = (_Float16)w;
                     const _Float16 lo = (_Float16)(w - (float)hi);
+                    const float res = w - ((float)hi + (float)lo);
+                    if (!((res < 0.0f ? -res : res) <= aw * 4.76837158e-7f + 5.96046448e-8f)) rc = -1;
                     const size_t o = (((size_t)s * 4 + c) * 64 + l) * 8 + j;
                     wl[o] = f16_bits(hi);
                     wl[(size_t)ROOT3_PART_U4 * 8 + o] = f16_bits(lo);
                 }
+    return rc;
 }
 
 // ================================ the root pass with the weights resident in registers =====================================

@@ -449,11 +449,17 @@ __global__ void rows_values_kernel(const uint4 *__restrict__ rows, const float *
 #endif
     if (b_base > 0) {
         long long k = 0, rest = r;
-        for (; k < N_ARENAS - 1; ++k) {
+        for (; k < N_ARENAS; ++k) {
             long long c = (long long)tops[arena_counter((int)k)];
             if (c > b_base) c = b_base;
             if (rest < c) break;
             rest -= c;
+        }
+        if (k == N_ARENAS) {                                    // past the rows the step produced (every arena clamped, the last one too):
+            if (st)                                             // zeros, never a read beyond the arenas
+                for (int j = 0; j < 28; ++j) st[i * 28 + j] = 0;
+            if (val) val[i] = 0.0f;
+            return;
         }
         r = k * b_base + rest;
     }
@@ -778,6 +784,7 @@ const char *bgamd_error_string(int code)
     case BGAMD_E_STATE: return "state with |count| > 15";
     case BGAMD_E_NOWEIGHTS: return "weights not loaded";
     case BGAMD_E_DELTA: return "incremental value net: a row differs from its root in more features than a legal turn changes";
+    case BGAMD_E_WEIGHTS: return "weights refused: a value is not finite or an fc1 weight is outside the f16 hi + lo range (|w| >= 65504)";
     default: return "unknown error";
     }
 }
@@ -1265,9 +1272,21 @@ int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choi
 
 int bgamd_env_load_weights(bgamd_env *env, const float *h_weights) { return bgamd_env_load_weights_slot(env, 0, h_weights); }
 
+// host only: do the 25 601 floats survive the value net's weight layouts?  (b1, W2, b2 stay fp32: they must be finite; W1 must fit the
+// f16 hi + lo planes of the root pass, bg_root_resident.h)
+int bgamd_weights_check(const float *h_weights)
+{
+    if (!h_weights) return BGAMD_E_INVALID;
+    for (int i = N_HID * N_IN; i < N_PARAMS; ++i)
+        if (!(h_weights[i] - h_weights[i] == 0.0f)) return BGAMD_E_WEIGHTS;
+    std::vector<uint16_t> planes((size_t)3 * K16_STEPS * 4 * 64 * 8);
+    return relayout_w1_f16x2_root(h_weights, planes.data()) < 0 ? BGAMD_E_WEIGHTS : BGAMD_OK;
+}
+
 int bgamd_env_load_weights_slot(bgamd_env *env, int slot, const float *h_weights)
 {
     if (!env || !h_weights || slot < 0 || slot > 1) return BGAMD_E_INVALID;
+    if (int rc = bgamd_weights_check(h_weights)) return rc;      // before anything of the slot is overwritten
     HIPCHK(hipSetDevice(env->device));
     std::vector<float> wl((size_t)K_STEPS * 64 * 4);
     relayout_w1_f32(h_weights, wl.data());
@@ -1413,6 +1432,9 @@ struct GreedyRun {
         root_ready = false;
         ev = env->v;
         if (env->ring_rows) {
+            // the ring log's contract (include/bgamd.h): every lane takes part in every logged step and restarts itself -- a game is the
+            // `length` contiguous slots that end at its end record.  Anything else would make the game table point at other games' rows.
+            if (!(fl & BGAMD_AUTO_RESET) || (fl & (BGAMD_ONLY_P1 | BGAMD_ONLY_P2))) return BGAMD_E_INVALID;
             ev.traj = env->ring_rows; ev.traj_plies = env->ring_steps; ev.traj_ring = env->ring_steps; ev.endrec = env->ring_end;
         }
         return BGAMD_OK;
@@ -1783,7 +1805,9 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
     hipStream_t s = (hipStream_t)stream;
     StagedView &sv = env->sv;
     const float *b1 = env->d_w[slot] + N_HID * N_IN, *w2 = b1 + N_HID, *b2 = w2 + N_HID;
-    // the env's root / afterstate arenas double as scratch, as the candidate arena does for bgamd_evaluate
+    // the env's root / afterstate arenas double as scratch, as the candidate arena does for bgamd_evaluate; the rows are written
+    // linearly from 0: a later unique_rows_read must not remap them through the arena counters of an earlier greedy step
+    sv.b_base = 0;
     hipLaunchKernelGGL(pack_rows_kernel, grid1(n_roots, 128), dim3(128), 0, s, d_root_states28, d_root_turn, (long long)n_roots,
                        sv.root_rows, &env->v.counters[C_ERR]);
     hipLaunchKernelGGL(pack_child_rows_kernel, grid1(n, 128), dim3(128), 0, s, d_states28, d_root_index, (long long)n,

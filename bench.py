@@ -9,13 +9,20 @@ of the slowest rank, states resident in HBM.  The K timed steps are ONE bgamd_en
 call (the same games as K step_greedy calls; consecutive steps share a launch); the dominant
 kernel is bracketed with HIP events on every 8th of those steps (every 4th in runs shorter than 80 steps; an event pair costs ~4 us).
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]            # N > 1: this process starts the N ranks itself (launch_ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # or a launcher does
+
+After the timed region (outside the contract's bracket) the line also carries `training_round`: configs 4/5's per-GPU share -- self-play
+with the turn log + the TD(lambda) replay, with ONE all-reduce of the 25 601-float update per training step when there is more than one rank.
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,15 +30,19 @@ for p in (ROOT, os.path.join(ROOT, "backgammon-engine_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# The step overlaps its root pass with the doubles plies on a second stream.  ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4)
-# hardware queues; an RCCL communicator brings streams of its own, the env's two then share a queue and the overlap is gone
-# (measured: 0.153 -> 0.167 ms per step with nothing but `init_process_group("nccl")` added; 0.153 again with 8 queues).
+# Streams of one process map onto GPU_MAX_HW_QUEUES (default 4) hardware queues; an RCCL communicator brings streams of its own.
+# The step itself runs on ONE stream since round 4; the training loop's learner has a second one (replay beside the next window).
 # Read when the HIP runtime starts, so it is set before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+np = torch = dist = None                    # numpy / torch / torch.distributed: imported by _heavy_imports() in a RANK, never in the launching parent
+
+
+def _heavy_imports():
+    global np, torch, dist
+    import numpy, torch as _torch, torch.distributed as _dist       # noqa: E401
+    np, torch, dist = numpy, _torch, _dist
+
 
 GAMES_PER_GPU = 65536
 SEED = 20240603
@@ -43,6 +54,105 @@ PEAK_LDS_TBPS = 157.3        # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz (t
 # output unit; per (row, changed feature): one 128-float W1 column = 128 FMAs
 FLOP_PER_ROW_EPILOGUE = 128 * 5 + 6
 FLOP_PER_COLUMN = 256
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
+    ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
+    ap.add_argument("--precision", choices=("f32", "f32_dense", "f16x2", "bf16"), default="f32",
+                    help="value-net arithmetic: f32 = fp32 FMAs, incremental hidden layer (headline); f32_dense = the dense fp32 "
+                         "MFMA chain over every afterstate; f16x2 = f16 hi+lo weight split, fp32 accumulate (also inside the "
+                         "1e-5 parity bound); bf16 = speed mode outside it")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--training-round", dest="training_round", action="store_true", default=True,
+                    help="(default) extra object in the line, measured AFTER the timed region: one training round of configs 4/5's per-GPU "
+                         "share (self-play with the turn log + TD(lambda) replay; one all-reduce per training step when world > 1)")
+    ap.add_argument("--no-training-round", dest="training_round", action="store_false",
+                    help="skip it: its self-play launches the step's kernels on shrinking batches, and a rocprofv3 --stats summary "
+                         "must average the timed workload only (tools/profile_round.sh and the A/B harness pass this)")
+    ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes, the training round and the CPU baseline, sample U on fewer lanes")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 started plainly: seconds before the parent's watchdog "
+                    "kills the ranks it started and reports")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv, child_cmd=None, timeout_s=1500.0, out=None, err=None):
+    """`python bench.py --gpus N` started PLAINLY (no WORLD_SIZE in the environment): this process -- which has imported neither torch nor
+    the HIP library and never touches the GPU -- starts the N ranks as CHILD processes (the reference starts its workers the same way: a
+    spawn pool, train.py:324-325,495-496), one process group each, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set, relays rank 0's stdout (the ONE JSON line) to its own, every rank's stderr (and the other ranks' stdout) to its
+    stderr, and returns the ranks' exit code: 0 only when every rank exited 0.  The first rank that fails takes the others down (SIGTERM to
+    exactly the process groups started here, SIGKILL 10 s later); so does the watchdog after timeout_s (-> 124).  Nothing is exec'ed or
+    retried.  child_cmd: the command of one rank (default: this interpreter on this file with the same arguments)."""
+    out = out or sys.stdout
+    err = err or sys.stderr
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__), *argv]
+    port = _free_port()
+    procs, pumps = [], []
+
+    def pump(src, dst, tag):
+        for line in iter(src.readline, b""):
+            dst.write((tag + line.decode(errors="replace")) if tag else line.decode(errors="replace"))
+            dst.flush()
+        src.close()
+
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY=str(os.getpid()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        procs.append(p)
+        for src, dst, tag in ((p.stdout, out if r == 0 else err, "" if r == 0 else f"[rank {r}] "), (p.stderr, err, f"[rank {r}] ")):
+            t = threading.Thread(target=pump, args=(src, dst, tag), daemon=True)
+            t.start()
+            pumps.append(t)
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)              # start_new_session: pgid == pid of the rank this process started
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    t0, rc, why = time.monotonic(), 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = (bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]), f"rank {bad[0][0]} exited with {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > timeout_s:
+            rc, why = 124, f"watchdog: ranks still running after {timeout_s:.0f} s"
+            break
+        time.sleep(0.05)
+    if why:
+        stop_all(signal.SIGTERM)
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10.0:
+            time.sleep(0.05)
+        stop_all(signal.SIGKILL)
+        for p in procs:
+            p.wait()
+    for t in pumps:
+        t.join(timeout=5.0)
+    if why:
+        err.write(f"bench.py launcher: {why}; exit codes by rank {[p.returncode for p in procs]}\n")
+        err.flush()
+    return rc
 
 
 def host_description():
@@ -145,36 +255,75 @@ def cpu_baseline(weights, budget_s=10.0):
     return out
 
 
-def training_round(bg, games, w):
+def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
     """Extra information (outside the timed region of the contract): one training round of configs 4/5's per-GPU share -- self-play
-    of `games` games with the turn log from a frozen snapshot (train.py:527-547), then the TD(lambda) replay of the round on the
+    of `games` games per rank with the turn log from a frozen snapshot (train.py:527-547), then the TD(lambda) replay of the round on the
     HIP learner kernels (bgamd_td_*): lock-step over the whole round, and streamed through 2 048 slots (the configuration the
-    quality study recommends: DESIGN.md §7).  Second run of each (the first pays allocations)."""
-    import torch
-    from backgammon_env.learner import DeviceTDLambdaLearner, play_round
-    env = bg.VecGame(games, seed=5)
+    quality study recommends: DESIGN.md §6).  Second run of each (the first pays allocations).
+
+    world > 1 (configs 4/5 as BASELINE lays them out; replaces the reference's spawn pool, train.py:324-325,495-496): every rank plays and
+    replays ITS shard (global game ids: shard_for_rank), every training step's 25 601-float update is all-reduced ONCE -- issued by the
+    library on the learner's own RCCL communicator (DeviceTDLambdaLearner.init_collective -> bgamd_td_replay_allreduce) with backend nccl,
+    through torch.distributed with the gloo rehearsal backend (ranks sharing a GPU cannot form an RCCL communicator) -- and the replicas'
+    weights are compared bit for bit at the end of every phase (MIN == MAX of a 64-bit checksum over the ranks).  Times are the MAX over
+    the ranks between barriers, turns and updates the SUM: round_turns_per_s is the whole job's."""
+    from backgammon_env.learner import ContinuousSelfPlay, DeviceTDLambdaLearner, play_round
+    from backgammon_env.shard import shard_for_rank
+    multi = world > 1
+    group = dist.group.WORLD if multi else None
+    cdev = torch.device("cuda", torch.cuda.current_device()) if (not multi or backend == "nccl") else torch.device("cpu")
+    off, stride = shard_for_rank(rank, world, games)
+    env = bg.VecGame(games, seed=5, lane_offset=off, lane_stride=stride)
     env.load_weights(w)
-    L = DeviceTDLambdaLearner(w, max_games=games, alpha=0.1, lam=0.7)
+
+    def learner(max_games):
+        L = DeviceTDLambdaLearner(w, max_games=max_games, alpha=0.1, lam=0.7)
+        if multi and backend == "nccl":
+            L.init_collective(group)
+        return L
+
+    def reduce(x, op):
+        if not multi:
+            return x
+        t = torch.tensor([x], dtype=torch.float64 if isinstance(x, float) else torch.int64, device=cdev)
+        dist.all_reduce(t, op=op, group=group)
+        return t.item()
 
     def timed(f):
+        if multi:
+            dist.barrier(group)
         torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize()
-        return r, time.perf_counter() - t0
+        return r, reduce(time.perf_counter() - t0, dist.ReduceOp.MAX if multi else None)
+
+    def replicas_identical(L):
+        """the ranks' weights, bit for bit: a 64-bit sum of the fp32 bit patterns, MIN == MAX over the ranks"""
+        cs = int(L.theta.view(torch.int32).to(torch.int64).sum().item())
+        return reduce(cs, dist.ReduceOp.MIN if multi else None) == reduce(cs, dist.ReduceOp.MAX if multi else None), cs
+
+    L = learner(games)
     for _ in range(2):
         (rows, lengths, won), dt_play = timed(lambda: play_round(env, max_plies=600, epsilon=0.05))
-    turns = int(lengths.sum().item())
-    out = {"games": games, "turns": turns, "selfplay_with_turn_log_ms": round(1e3 * dt_play, 2)}
+    turns = reduce(int(lengths.sum().item()), dist.ReduceOp.SUM if multi else None)
+    out = {"games": games * world, "games_per_rank": games, "ranks": world, "turns": turns, "selfplay_with_turn_log_ms": round(1e3 * dt_play, 2),
+           "collective": ("none (one rank)" if not multi else "in-library ncclAllReduce (bgamd_td_replay_allreduce)" if backend == "nccl"
+                          else "torch.distributed all_reduce over %s (rehearsal)" % backend) + ("" if not multi else ", one per training step")}
+    ident = True
     for name, kw in (("lockstep_whole_round", {}), ("streamed_2048_slots", {"slots": 2048})):
         for _ in range(2):
             L.set_weights(w)
-            (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, batch_scale=24.0 / (kw.get("slots") or games), **kw))
+            (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, group=group,
+                                                        batch_scale=24.0 / (world * (kw.get("slots") or games)), **kw))
+        cnt = reduce(cnt, dist.ReduceOp.SUM if multi else None)
+        same, cs = replicas_identical(L)
+        ident = ident and same
         out[name] = {"replay_ms": round(1e3 * dt, 2), "td_updates_per_s": round(cnt / dt, 1),
-                     "round_turns_per_s": round(turns / (dt + dt_play), 1)}
+                     "round_turns_per_s": round(turns / (dt + dt_play), 1), "weights_checksum": "%016x" % (cs & (2 ** 64 - 1))}
+    del L
     # round 4: continuous self-play (every lane restarts the step after its game ended; ring log by env step) in windows of 84 steps of all
     # lanes -- about as many turns as a round -- with the replay of the games that ended in the window after it, and BESIDE the next window
-    # (learner on its own stream and host thread; tools/train_pipeline.py is the stand-alone A/B, DESIGN.md §7 the numbers)
-    import threading
-    from backgammon_env.learner import ContinuousSelfPlay
-    L = DeviceTDLambdaLearner(w, max_games=2048, alpha=0.1, lam=0.7)
+    # (learner on its own stream and host thread; tools/train_pipeline.py is the stand-alone A/B, DESIGN.md §6 the numbers).  With more than one
+    # rank every rank joins every window's collectives (replay_games handles a window without finished games).
+    L = learner(2048)
     side = torch.cuda.Stream()
     dev_i = torch.cuda.current_device()
     for pipe in (False, True):
@@ -184,10 +333,12 @@ def training_round(bg, games, w):
         def replay(tab):
             torch.cuda.set_device(dev_i)
             with torch.cuda.stream(side):
-                res["r"] = L.replay_games(sp.rows, *tab, slots=2048, batch_scale=24.0 / 2048)
+                res["r"] = L.replay_games(sp.rows, *tab, slots=2048, group=group, batch_scale=24.0 / (world * 2048))
             side.synchronize()
         pending = None
         for r in range(8):
+            if multi:
+                dist.barrier(group)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             th = None
             if pipe and pending is not None:
@@ -204,11 +355,15 @@ def training_round(bg, games, w):
             torch.cuda.synchronize()
             if r >= 4:
                 times.append(time.perf_counter() - t0)
-        ms, trn = 1e3 * float(np.median(times)), res["r"][1]
+        ms = reduce(1e3 * float(np.median(times)), dist.ReduceOp.MAX if multi else None)
+        trn = reduce(int(res["r"][1]), dist.ReduceOp.SUM if multi else None)
+        same, cs = replicas_identical(L)
+        ident = ident and same
         out["continuous_window_84_steps" + ("_replay_beside_the_next_window" if pipe else "")] = {
             "window_ms": round(ms, 2), "selfplay_ms": round(1e3 * float(np.median(t_play[4:])), 2) if not pipe else None,
-            "turns_replayed": trn, "round_turns_per_s": round(trn / ms * 1e3, 1)}
+            "turns_replayed": trn, "round_turns_per_s": round(trn / ms * 1e3, 1), "weights_checksum": "%016x" % (cs & (2 ** 64 - 1))}
         sp.close()
+    out["replicas_identical"] = bool(ident)
     del L, env
     return out
 
@@ -232,32 +387,21 @@ def distinct_ratio(env, prec, sample_lanes=2048, samples=4):
     return u / lanes, c / lanes              # distinct afterstates and raw candidates per env step
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
-    ap.add_argument("--burnin", type=int, default=160, help="untimed steps that de-phase the games (input preparation)")
-    ap.add_argument("--precision", choices=("f32", "f32_dense", "f16x2", "bf16"), default="f32",
-                    help="value-net arithmetic: f32 = fp32 FMAs, incremental hidden layer (headline); f32_dense = the dense fp32 "
-                         "MFMA chain over every afterstate; f16x2 = f16 hi+lo weight split, fp32 accumulate (also inside the "
-                         "1e-5 parity bound); bf16 = speed mode outside it")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) | gloo (rehearsal: ranks may share a GPU)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--training-round", action="store_true", help="extra object in the line: one training round of configs 4/5's per-GPU share "
-                    "(self-play with the turn log + TD(lambda) replay).  Off by default: its self-play launches the step's kernels on shrinking "
-                    "batches, and a rocprofv3 --stats summary of the default command must average the timed workload only")
-    ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes and the CPU baseline, sample U on fewer lanes")
-    a = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    if a.quick:
+        a.training_round = False
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # started plainly: this process becomes the launcher of the N ranks and nothing else (no torch, no HIP in it)
+        sys.exit(launch_ranks(a.gpus, argv, timeout_s=a.launch_timeout))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) or with --nproc-per-node {a.gpus}")
+    _heavy_imports()
     dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -275,7 +419,7 @@ def main():
     if use_dist:
         dist.barrier()
     import backgammon_env as bg
-    from backgammon_env.shard import aggregate, shard_for_rank
+    from backgammon_env.shard import aggregate, census, shard_for_rank
 
     w = np.fromfile(os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32"), dtype=np.float32)
     off, stride = shard_for_rank(rank, world, a.games)
@@ -335,10 +479,22 @@ def main():
             if k != "eval":
                 kt[k] = kt2[k]
 
+    cdev = dev if a.dist_backend == "nccl" else None
     tot, t_max = aggregate({k: int(round(st[k])) for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated", "ksteps_executed")},
-                           elapsed, device=dev if a.dist_backend == "nccl" else None)
+                           elapsed, device=cdev)
+    ranks_seen, per_rank_s = census(elapsed, device=cdev)      # how many ranks this process group really has, and each one's median region
+    # configs 4/5's per-GPU share, on EVERY rank (its replay's collectives are joined by all of them); outside the contract's bracket
+    tr = None
+    if a.training_round and a.games >= 4096:
+        try:
+            tr = training_round(bg, a.games, w, rank, world, a.dist_backend)
+        except Exception as e:                                  # extra information only: never costs the bench line
+            if world > 1:
+                raise                                           # ... unless ranks could be left waiting in a collective: fail loudly, the launcher reports
+            tr = {"error": repr(e)[:200]}
     if rank != 0:
         if use_dist:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -361,7 +517,7 @@ def main():
                        "inside the 1e-5 parity bound like f32; bf16 = speed mode outside it (1.2e-3)")
     out = {
         "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
-        "unit": "env steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "unit": "env steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if a.precision == "f32_dense" else a.precision, "data": "synthetic",
         "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
@@ -474,15 +630,18 @@ def main():
                               gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
     if alt:
         out["alt_modes"] = alt
-    if world == 1 and a.training_round and a.games >= 4096:
-        try:
-            out["training_round"] = training_round(bg, a.games, w)
-        except Exception as e:                                  # extra information only: never costs the bench line
-            out["training_round"] = {"error": repr(e)[:200]}
+    if tr is not None:
+        out["training_round"] = tr
     if world == 1 and not a.no_cpu_baseline and not a.quick:
         out["cpu_baseline"] = cpu_baseline(w)
+    if world > 1:
+        ms = [1e3 * t / a.steps for t in per_rank_s]
+        out["per_rank_ms_per_step"] = {"min": round(min(ms), 4), "max": round(max(ms), 4), "by_rank": [round(x, 4) for x in ms]}
+        out["dist_backend"] = a.dist_backend
+        out["launched_by"] = "bench.py launch_ranks" if os.environ.get("BENCH_LAUNCHED_BY") else "external launcher"
     print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -42,6 +42,9 @@ def run_continuous(a, env, arena, L, group, world, prec, say, n_classic=0, t0=No
     import threading
     from backgammon_env.learner import ContinuousSelfPlay
     assert a.slots > 0 and not a.host_learner, "--continuous replays streamed through --slots on the device learner"
+    # pipelined windows do not all-reduce the finished-game count (the learner's thread owns the process group): with more than one rank
+    # the hold decision could then differ between ranks and leave one of them out of a replay's collectives -- refused
+    assert not (world > 1 and a.pipeline_rounds and a.min_window_games > 0), "--min-window-games with --pipeline-rounds needs a single rank"
     dist = torch.distributed if world > 1 else None
     sp = ContinuousSelfPlay(env, ring_steps=a.ring_steps, episode=n_classic)      # (the classic rounds played episodes 0 .. n_classic - 1)
     L.set_delay(a.update_delay)
@@ -62,7 +65,7 @@ def run_continuous(a, env, arena, L, group, world, prec, say, n_classic=0, t0=No
             env.load_weights(L.theta.cpu().numpy())
         sp.play(a.window_steps, epsilon=a.eps if a.eps is not None else a.eps_start, precision=prec)
         sp.finished()
-    held = None                                        # finished games held back until --min-window-games have accumulated
+    held, held_all = None, 0                           # finished games held back until --min-window-games (per rank, summed over the ranks) have accumulated
     pending, th = None, None
     n_win = a.rounds - n_classic
     for r in range(n_win + (1 if a.pipeline_rounds else 0)):
@@ -90,8 +93,13 @@ def run_continuous(a, env, arena, L, group, world, prec, say, n_classic=0, t0=No
             if held is not None:
                 table = tuple(torch.cat([h, t]) for h, t in zip(held, table))
                 held = None
-            if int(table[0].numel()) < a.min_window_games and r + 1 < n_win:
+            # hold or replay is ONE decision for all ranks (a rank that holds while another replays would miss the replay's collectives):
+            # taken from the all-reduced count -- the games of this window plus what every rank already holds
+            held_all += int(n_fin.item())
+            if held_all < a.min_window_games * world and r + 1 < n_win:
                 held, table = table, None              # too few games for a replay of their own: they go with the next window's
+            else:
+                held_all = 0
         if a.pipeline_rounds:
             if th is not None:
                 th.join()

@@ -35,8 +35,10 @@ enum {
     BGAMD_E_ARENA = -4,       /* candidate arena overflow (raise arena_rows)          */
     BGAMD_E_STATE = -5,       /* a state had |count| > 15                             */
     BGAMD_E_NOWEIGHTS = -6,   /* greedy step / evaluate before bgamd_env_load_weights */
-    BGAMD_E_DELTA = -7        /* an afterstate differed from its root position in more features than a legal turn
+    BGAMD_E_DELTA = -7,       /* an afterstate differed from its root position in more features than a legal turn
                                  can change (incremental value net): the rows handed to it are not afterstates  */
+    BGAMD_E_WEIGHTS = -8      /* a weight is not finite, or an fc1 weight does not fit the f16 hi + lo planes of the value
+                                 net's root pass (|w| >= 65 504): nothing was loaded                            */
 };
 
 /* step flags */
@@ -172,6 +174,10 @@ int bgamd_env_step_random(bgamd_env *env, int flags, const uint32_t *d_choice_u3
 int bgamd_env_step_random_walk(bgamd_env *env, int flags, const uint32_t *d_choice_u32, void *stream);
 int bgamd_env_load_weights(bgamd_env *env, const float *h_weights /* 25601: W1[128][198] b1 W2 b2 */);   /* slot 0 */
 int bgamd_env_load_weights_slot(bgamd_env *env, int slot /* 0 | 1 */, const float *h_weights);
+/* host only (no device needed): would bgamd_env_load_weights accept these 25 601 floats?  BGAMD_OK | BGAMD_E_WEIGHTS.  The reference's
+ * model takes any fp32 state_dict (model.py:36-37); the value net's root pass here multiplies fc1.weight as f16 hi + f16 lo planes, exact
+ * for 22 mantissa bits up to |w| < 65 504 -- a table beyond that (a diverged run) is refused loudly instead of evaluated as NaN. */
+int bgamd_weights_check(const float *h_weights);
 int bgamd_env_step_greedy(bgamd_env *env, int flags, float epsilon, int precision, void *stream);
 /* n_steps greedy steps back to back (the loop body of play_game, train.py:103-121, n_steps times for every lane),
  * identical in effect to n_steps calls of bgamd_env_step_greedy; between two steps of a run the apply of one and the
@@ -225,7 +231,10 @@ int bgamd_env_get_progress(bgamd_env *env, int32_t *d_ply, int32_t *d_episode, v
  * Only greedy steps (bgamd_env_step_greedy / run_greedy) log into the ring; every lane must take part in every step (no
  * BGAMD_ONLY_P1/P2).  Every game is one episode of one lane: the same game bgamd_env_reset_episode + a run to the end plays with the
  * same weights.  A caller that refreshes the weights between runs lets the games in flight go on under the new ones (TD-Gammon's own
- * self-play changes the weights after every move).  NULL disables.  bgamd_env_trajectory_step: env steps logged since the call. */
+ * self-play changes the weights after every move).  NULL disables.  bgamd_env_trajectory_step: env steps logged since the call.
+ * Enforced (round 5): with a ring set, a greedy step without BGAMD_AUTO_RESET or with BGAMD_ONLY_P1/P2 returns BGAMD_E_INVALID.
+ * bgamd_env_trajectory_step is a HOST counter bumped when a run is ENQUEUED: read the end records on the stream the run was issued on (or
+ * after synchronising it) -- ContinuousSelfPlay.finished() does the former. */
 int bgamd_env_set_trajectory_ring(bgamd_env *env, void *d_rows, int64_t ring_steps, uint16_t *d_end);
 int64_t bgamd_env_trajectory_step(const bgamd_env *env);
 int bgamd_encode_rows(const void *d_rows, int64_t n, float *d_out198, void *stream);

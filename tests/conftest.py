@@ -13,7 +13,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def _wants_experimental(config):
-    return "gpu_experimental" in (config.getoption("-m") or "")
+    """True when the -m expression SELECTS tests because they carry gpu_experimental (`-m gpu_experimental`), not when it merely names the
+    marker: `-m "not gpu_experimental"` / `-m "gpu and not gpu_experimental"` run the default build.  The expression is
+    evaluated: it must hold for an item marked gpu_experimental only and fail for an unmarked one."""
+    expr = config.getoption("-m") or ""
+    if "gpu_experimental" not in expr:
+        return False
+    try:
+        from _pytest.mark.expression import Expression
+        e = Expression.compile(expr)
+        return bool(e.evaluate(lambda name, **kw: name == "gpu_experimental")) and not bool(e.evaluate(lambda name, **kw: False))
+    except Exception:                                    # a pytest without that module: fall back to asking for the marker alone
+        return expr.strip() == "gpu_experimental"
 
 
 def pytest_configure(config):

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -153,3 +155,31 @@ def test_pybind_module_has_the_reference_surface(built):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.split()
     assert lines[0] == "OK" and lines[1] == built.source_hash()
+
+
+def test_weights_outside_the_f16_split_are_refused(built):
+    """the root pass multiplies fc1.weight as f16 hi + f16 lo planes; a table with |w| >= 65 504 (hi = inf, lo = NaN), a weight the
+    split cannot hold, or a non-finite value anywhere must be refused loudly (BGAMD_E_WEIGHTS = -8), host side, before anything is loaded.
+    The reference checkpoint and tables of ordinary size pass."""
+    lib = built.load()
+    w = np.fromfile(os.path.join(ROOT, "tests", "golden", "tdgammonNEW100k.f32"), dtype=np.float32)
+
+    def chk(x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return lib.bgamd_weights_check(x.ctypes.data_as(ctypes.c_void_p))
+    assert chk(w) == 0
+    rng = np.random.default_rng(1)
+    assert chk((rng.standard_normal(25601) * 30).astype(np.float32)) == 0          # any ordinary table: 22 mantissa bits hold
+    for idx, val in ((17, 65520.0), (17, -7.0e4), (198 * 5 + 3, np.inf), (0, np.nan), (25344 + 5, np.nan), (25600, np.inf)):
+        bad = w.copy()
+        bad[idx] = val
+        assert chk(bad) == -8, (idx, val)
+    ok = w.copy()
+    ok[17] = 60000.0                                                               # inside the f16 range
+    assert chk(ok) == 0
+    big15 = w.copy()
+    big15[197] = 15 * 60000.0                                                      # features 196/197 carry w / 15 (the count's 1/15 is folded in)
+    assert chk(big15) == 0
+    big15[197] = 15 * 70000.0
+    assert chk(big15) == -8
+    assert b"65504" in lib.bgamd_error_string(-8)
