@@ -285,7 +285,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_rows_f32_kernel(
 // in fp32 FMAs; hidden sigmoid, W2 dot, output sigmoid and the per-game arg-max are as in the dense kernel.
 // Lane = row, 32 hidden units at a time in registers, W1^T in LDS (132-float row stride), each lane's (row, Δ) list in LDS.
 // The sum is the same real number as the dense chain with a different association: values agree to ~1e-7.
-constexpr int DELTA_THREADS = 1024;                     // 16 waves per CU, one workgroup per CU (LDS: W1^T + the lists)
+#ifndef BG_DELTA_THREADS
+#define BG_DELTA_THREADS 1024
+#endif
+constexpr int DELTA_THREADS = BG_DELTA_THREADS;         // 16 waves per CU, one workgroup per CU (LDS: W1^T + the lists).  -DBG_DELTA_THREADS=512/768: the round-5
+                                                        // co-residency experiment (2 / 3 waves per SIMD at 128 VGPRs: room for another kernel's workgroup on the CU)
 #ifndef BG_DW_STRIDE
 #define BG_DW_STRIDE 132
 #endif
@@ -391,7 +395,12 @@ __device__ __forceinline__ f32x2_t delta_sigmoid_pair(f32x2_t a, f32x2_t w, f32x
                                                      //  needs a wait state on gfx950, which the compiler inserts)
 }
 
-__global__ __launch_bounds__(DELTA_THREADS) void eval_rows_delta_kernel(
+#if BG_DELTA_THREADS == 1024
+#define BG_DELTA_BOUNDS __launch_bounds__(DELTA_THREADS)
+#else
+#define BG_DELTA_BOUNDS __launch_bounds__(DELTA_THREADS, 4)       /* still 128 VGPRs: the freed half of the register file is for the neighbour */
+#endif
+__global__ BG_DELTA_BOUNDS void eval_rows_delta_kernel(
     const uint4 *__restrict__ rows, const unsigned long long *__restrict__ n_rows_ptr, long long n_rows_imm,
     unsigned long long *__restrict__ rows_eval_counter, const float4 *__restrict__ wt, const float *__restrict__ w2,
     const float *__restrict__ b2p, const uint4 *__restrict__ root_rows, const float *__restrict__ root_hidden,

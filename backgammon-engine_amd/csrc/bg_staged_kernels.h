@@ -500,6 +500,7 @@ __device__ __forceinline__ unsigned long long nodes_per_block(unsigned long long
     return npb < 64 ? 64 : (npb > (unsigned long long)nt ? (unsigned long long)nt : npb);
 }
 
+#ifdef BGAMD_EXPERIMENTAL          // rounds 1-4's two launches below the roots: bit-identity references of expand_all_kernel (round 5: experimental build only)
 // leaf stage (and a single doubles ply, kept for tests and experiments)
 template <int MODE>
 __global__ __launch_bounds__(expand_threads(MODE)) void expand_kernel(EnvView e, StagedView sv)
@@ -566,8 +567,9 @@ __global__ __launch_bounds__(expand_threads(MODE_PLY2)) void doubles_kernel(EnvV
         }
     }
 }
+#endif  // BGAMD_EXPERIMENTAL
 
-// The whole expansion below the roots in ONE launch (round 4; the default: BGAMD_EXPAND_MERGED=0 brings the two launches back).
+// The whole expansion below the roots in ONE launch (round 4; the experimental build's BGAMD_EXPAND_MERGED=0 brings the two launches back).
 // The doubles plies (28 k + 45 k nodes at 65 536 lanes) are a chain of latencies that leaves most of the chip idle, and the leaf
 // stage of the NON-doubles turns -- three fifths of the leaf stage -- does not depend on them: its parents are written by the roots.
 //   workgroups [0, n_dbl)       a share of the doubles turns' ply-1 nodes through ply 2, ply 3 AND their leaf stage, one phase

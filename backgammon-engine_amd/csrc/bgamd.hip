@@ -834,14 +834,17 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
 #endif
     // Where the root pass runs (round 4, profiles/r04_lanes_32768_anatomy.txt, r04_ab_root_pass_in_boundary.txt): inside the boundary launch from 24 576 lanes
     // -- there a boundary workgroup owns 128 games (BROOT_GPW), so 32 768 lanes still put a workgroup on every CU: 94.5 vs 98.7 us per step with the pass as a
-    // launch of its own (65 536: 143.2 vs 143.6; 16 384: 72.0 vs 71.7, a tie: smaller envs keep the launch) -- and never on a second stream unless asked
-    // (BGAMD_OVERLAP=1): since the resident root pass the fork is worth nothing at any size (16 384: 76.5 vs 70.5 us the other way, 32 768: 101.1 vs 97.5).
-    // BGAMD_ROOT_IN_BOUNDARY=0 / =1 force either.
+    // launch of its own (65 536: 143.2 vs 143.6; 16 384: 72.0 vs 71.7, a tie: smaller envs keep the launch) -- and always on the caller's stream.
+    env->root_in_boundary = n_games >= 24576 && LANE_NT == BROOT_THREADS;
+    env->overlap = false;
+#ifdef BGAMD_EXPERIMENTAL
+    // Round 5: the launch structures that lost their A/B (rounds 1-4) are honoured by the EXPERIMENTAL build only, as bit-identity references
+    // (tests/test_gpu_experimental.py): the root pass forced in / out of the boundary launch (BGAMD_ROOT_IN_BOUNDARY) or forked onto the env's second
+    // stream (BGAMD_OVERLAP), the expansion as two launches (BGAMD_EXPAND_MERGED=0), one row arena (BGAMD_SPLIT_ARENA=0), unsharded node lists
+    // (BGAMD_LIST_SHARDS=0), and the expansion launch's timing knobs.  The default build reads none of them.
     {
         const char *rib = getenv("BGAMD_ROOT_IN_BOUNDARY");
-        env->root_in_boundary = (rib ? atoi(rib) != 0 : n_games >= 24576) && LANE_NT == BROOT_THREADS;
-    }
-    {
+        if (rib) env->root_in_boundary = atoi(rib) != 0 && LANE_NT == BROOT_THREADS;
         const char *xm = getenv("BGAMD_EXPAND_MERGED");
         env->expand_merged = xm ? atoi(xm) != 0 : true;
         const char *xp = getenv("BGAMD_EXPAND_DBL_PCT");
@@ -856,6 +859,7 @@ int bgamd_env_create(bgamd_env **out, int64_t n_games, int device, uint64_t seed
         if (xn && atoi(xn) >= 64 && atoi(xn) <= XALL_NT) env->expand_dbl_npb = atoi(xn) & ~63;
     }
     env->overlap = getenv("BGAMD_NO_OVERLAP") == nullptr && getenv("BGAMD_OVERLAP") != nullptr && atoi(getenv("BGAMD_OVERLAP")) != 0;
+#endif
     if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -1411,7 +1415,11 @@ struct GreedyRun {
         sv.b_base = (incremental && env->split_arena) ? (env->sv.cap_rows / N_ARENAS) & ~63ll : 0;
         {   // grid of expand_all_kernel: two 512-thread workgroups per CU are resident, the first xall_nd take the doubles turns (one of each kind
             // per CU at the default share); the roots' lists in LIST_SHARDS parts when both counts divide
+#ifdef BG_XALL_WG_PER_CU                                                                     // (the round-5 co-residency experiment: fewer, so that one fits beside a value-net workgroup)
+            const long long n = env->v.n, slots = (long long)BG_XALL_WG_PER_CU * (long long)env->n_cu;
+#else
             const long long n = env->v.n, slots = (1024 / XALL_NT) * (long long)env->n_cu;       // 16 waves of expand_all_kernel per CU
+#endif
             long long nd = (n * 4 + 63) / 64;                       // doubles: ~64 ply-1 nodes per workgroup in a small env (a sixth of the lanes x <= 15)
             // the share of workgroups for the doubles turns: BGAMD_EXPAND_DBL_PCT, else by env size -- the doubles chains are what the launch waits
             // for, and the fewer lanes, the more so (32 768 lanes: 70 % 22.9 us, 50 % 25.1; 65 536: 62 % 28.5, 50 % 29.2; 16 384: 50 % 20.7, 63 % 21.3)
@@ -1515,15 +1523,8 @@ struct GreedyRun {
         }
         StagedView sv_next = sv;
         sv_next.tops = env->tops_base + (parity ^ 1) * T_COUNT;
-        if (env->expand_merged) {
-            // one launch: the doubles turns' plies 2, 3 and leaf stage on the first workgroups, the non-doubles leaf stage on the others
-            // (two 512-thread workgroups per CU are resident: one of each kind per CU at the default share)
-            KTimer t(env, s, 5);
-            const long long nd = xall_nd, grid = xall_nd + xall_nl;
-            hipLaunchKernelGGL(expand_all_kernel, dim3((unsigned)grid), dim3(XALL_NT), 0, s, ev, sv, (unsigned)nd,
-                               (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts, more ? sv_next.tops : (unsigned long long *)nullptr,
-                               (int)T_COUNT);
-        } else {
+#ifdef BGAMD_EXPERIMENTAL
+        if (!env->expand_merged) {                             // rounds 1-4's two launches (bit-identity reference)
             {
                 KTimer t(env, s, 4);
                 hipLaunchKernelGGL(doubles_kernel, egrid(n * 4, MODE_PLY2, ss.n_cu), dim3(expand_threads(MODE_PLY2)), 0, s, ev, sv);
@@ -1532,6 +1533,16 @@ struct GreedyRun {
                 KTimer t(env, s, 5);
                 hipLaunchKernelGGL(expand_kernel<MODE_LEAF>, egrid(n * 16, MODE_LEAF, ss.n_cu), dim3(expand_threads(MODE_LEAF)), 0, s, ev, sv);
             }
+        } else
+#endif
+        {
+            // one launch: the doubles turns' plies 2, 3 and leaf stage on the first workgroups, the non-doubles leaf stage on the others
+            // (two 512-thread workgroups per CU are resident: one of each kind per CU at the default share)
+            KTimer t(env, s, 5);
+            const long long nd = xall_nd, grid = xall_nd + xall_nl;
+            hipLaunchKernelGGL(expand_all_kernel, dim3((unsigned)grid), dim3(XALL_NT), 0, s, ev, sv, (unsigned)nd,
+                               (unsigned)env->expand_dbl_npb, (unsigned)env->expand_parts, more ? sv_next.tops : (unsigned long long *)nullptr,
+                               (int)T_COUNT);
         }
         // inside a run the apply of this step and the roots of the next share a launch; the counter set those roots allocate from is cleared
         // earlier in THIS step, while nothing uses it: by the expansion launch (every value-net mode), else by the incremental value net

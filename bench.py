@@ -76,6 +76,8 @@ def parse_args(argv=None):
                     help="skip it: its self-play launches the step's kernels on shrinking batches, and a rocprofv3 --stats summary "
                          "must average the timed workload only (tools/profile_round.sh and the A/B harness pass this)")
     ap.add_argument("--quick", action="store_true", help="A/B runs: skip the other value-net modes, the training round and the CPU baseline, sample U on fewer lanes")
+    ap.add_argument("--training-round-timeout", type=float, default=300.0, help="seconds before a training round that does not finish is "
+                    "abandoned (the line is printed without it)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 started plainly: seconds before the parent's watchdog "
                     "kills the ranks it started and reports")
     return ap.parse_args(argv)
@@ -276,18 +278,28 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
     env = bg.VecGame(games, seed=5, lane_offset=off, lane_stride=stride)
     env.load_weights(w)
 
-    def learner(max_games):
-        L = DeviceTDLambdaLearner(w, max_games=max_games, alpha=0.1, lam=0.7)
-        if multi and backend == "nccl":
-            L.init_collective(group)
-        return L
-
     def reduce(x, op):
         if not multi:
             return x
         t = torch.tensor([x], dtype=torch.float64 if isinstance(x, float) else torch.int64, device=cdev)
         dist.all_reduce(t, op=op, group=group)
         return t.item()
+
+    coll = {"in_library": multi and backend == "nccl", "note": None}
+
+    def learner(max_games):
+        L = DeviceTDLambdaLearner(w, max_games=max_games, alpha=0.1, lam=0.7)
+        if coll["in_library"]:
+            ok = 1
+            try:
+                L.init_collective(group)                   # an RCCL communicator of the learner's own beside torch's
+            except Exception as e:
+                ok, coll["note"] = 0, repr(e)[:200]
+            if reduce(ok, dist.ReduceOp.MIN) == 0:         # one decision for all ranks: the per-step all-reduce goes through torch.distributed instead
+                L._comm = None
+                coll["in_library"] = False
+                coll["note"] = coll["note"] or "another rank could not create the learner's communicator"
+        return L
 
     def timed(f):
         if multi:
@@ -305,8 +317,7 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
         (rows, lengths, won), dt_play = timed(lambda: play_round(env, max_plies=600, epsilon=0.05))
     turns = reduce(int(lengths.sum().item()), dist.ReduceOp.SUM if multi else None)
     out = {"games": games * world, "games_per_rank": games, "ranks": world, "turns": turns, "selfplay_with_turn_log_ms": round(1e3 * dt_play, 2),
-           "collective": ("none (one rank)" if not multi else "in-library ncclAllReduce (bgamd_td_replay_allreduce)" if backend == "nccl"
-                          else "torch.distributed all_reduce over %s (rehearsal)" % backend) + ("" if not multi else ", one per training step")}
+           "collective": None}
     ident = True
     for name, kw in (("lockstep_whole_round", {}), ("streamed_2048_slots", {"slots": 2048})):
         for _ in range(2):
@@ -364,6 +375,10 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
             "turns_replayed": trn, "round_turns_per_s": round(trn / ms * 1e3, 1), "weights_checksum": "%016x" % (cs & (2 ** 64 - 1))}
         sp.close()
     out["replicas_identical"] = bool(ident)
+    out["collective"] = ("none (one rank)" if not multi else "in-library ncclAllReduce (bgamd_td_replay_allreduce)" if coll["in_library"]
+                         else "torch.distributed all_reduce over %s%s" % (backend, " (rehearsal)" if backend != "nccl" else "")) + \
+                        ("" if not multi else ", one per training step")
+    out["collective_note"] = coll["note"]
     del L, env
     return out
 
@@ -483,162 +498,196 @@ def main(argv=None):
     tot, t_max = aggregate({k: int(round(st[k])) for k in ("steps", "games_finished", "candidates_raw", "rows_evaluated", "ksteps_executed")},
                            elapsed, device=cdev)
     ranks_seen, per_rank_s = census(elapsed, device=cdev)      # how many ranks this process group really has, and each one's median region
-    # configs 4/5's per-GPU share, on EVERY rank (its replay's collectives are joined by all of them); outside the contract's bracket
+    def build_line():
+        """rank 0: everything of the line but the training round and the CPU baseline"""
+        u_step, c_step = distinct_ratio(env, prec, samples=1 if a.quick else 4)
+        # the other value-net modes on the same env (untimed region of the contract: extra information only)
+        alt = {}
+        if world == 1 and not a.quick:
+            for name, pm in (("f32", bg.F32), ("f32_dense", bg.F32_DENSE), ("f16x2", bg.F16X2), ("bf16", bg.BF16)):
+                if name == a.precision:
+                    continue
+                env.run_greedy(10, precision=pm)
+                torch.cuda.synchronize()
+                s0, t1 = env.stats()["steps"], time.perf_counter()
+                env.run_greedy(100, precision=pm)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                alt[name] = {"env_steps_per_s": round((env.stats()["steps"] - s0) / dt, 1), "ms_per_step": round(10 * dt, 4)}
+            alt["note"] = ("f32_dense = dense v_mfma_f32_32x32x2_f32 chain over every afterstate (the r01 v6 headline path); "
+                           "f16x2 = W1 as f16 hi+lo (22 mantissa bits), exact products, fp32 accumulate: max |value - reference| 3e-7, "
+                           "inside the 1e-5 parity bound like f32; bf16 = speed mode outside it (1.2e-3)")
+        out = {
+            "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
+            "unit": "env steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if a.precision == "f32_dense" else a.precision, "data": "synthetic",
+            "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
+                                   "(tdgammonNEW100k weights), auto-reset, Philox dice",
+                       "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
+                       "raw_candidates_per_step": round(c_step, 2), "distinct_afterstates_per_step": round(u_step, 2),
+                       "staged_leaves_per_step": round(tot["candidates_raw"] / max(tot["steps"], 1), 2),
+                       "rows_evaluated_per_step": round(tot["rows_evaluated"] / max(tot["steps"], 1), 2),
+                       "games_finished": tot["games_finished"]},
+            # the timed region, as measured: every region is EXACTLY `steps` steps; more than one when the first was < 10 ms
+            "timed_regions": len(regions), "region_ms": {"min": round(1e3 * min(regions), 4), "median": round(1e3 * elapsed, 4),
+                                                         "max": round(1e3 * max(regions), 4)},
+            "source_hash": bg._capi.source_hash(), "library_build": bg._capi.load().bgamd_build_flags().decode(),
+        }
+        if kt:
+            nl = a.steps                                  # launches of the value-net kernel in the timed region (one per step)
+            # per-step GPU time of each kernel group: the value net as the mean of its bracketed launches in the timed
+            # region; the others from the short extra pass (a group may be bracketed more than once per step)
+            per = {k: (v["ms"] / (v["launches"] if k == "eval" else max(kt2["eval"]["launches"], 1)) if v["launches"] else 0.0)
+                   for k, v in kt.items()}
+            rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
+            fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
+            # distinct afterstates per launch: U per step sampled on 4 x 2 048 positions after the run, never more than the
+            # rows the launch actually evaluated (every distinct afterstate is one of them)
+            u_l = min(steps_l * u_step, rows_l)
+            eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+            # algorithmic bytes (DESIGN.md): leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
+            # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
+            merged = choice["expand"] == "expand_all_kernel"      # one launch for the doubles plies AND the leaf stage: both byte counts, one time
+            dbl_bytes = (fn_l + 2 * dn_l) * 8 + dn_l * 44
+            leaves_gbs = (fn_l * 52 + u_l * 40 + (dbl_bytes if merged else 0)) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
+            expand_gbs = (steps_l * 52 + dbl_bytes) / (per["expand"] * 1e-3) / 1e9 if per["expand"] and not merged else 0.0
+            ks_l = st.get("ksteps_executed", 0) / nl
+            peak = PEAK["f32" if a.precision == "f32_dense" else a.precision]
+            ev = {"bound": "mfma", "achieved": round(eval_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(eval_tf / peak, 4),
+                  "traffic": None, "avg_ms": round(per["eval"], 4), "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)}
+            if a.precision == "f32":
+                # The incremental evaluator executes no MFMA: its work is fp32 VALU arithmetic on W1 columns gathered from
+                # LDS, so THAT is the roof it is measured against: executed flop / kernel time over the fp32 vector peak.
+                # (The dense-equivalent figure -- SURVEY 8d's 50 944 flop per distinct afterstate -- stays as
+                # dense_equiv_tflops: it says how much faster than a perfect dense fp32 MFMA evaluation the stage is, and
+                # is not a fraction of anything.)  The per-game root pass is its own kernel (timed in slot "root").
+                exec_tf = (ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE) / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+                root_inside = choice["root"] == "inside boundary_kernel<true>"     # no launch of its own: the boundary launch's time holds it
+                root_tf = steps_l * FLOP_PER_ROW / (per["root"] * 1e-3) / 1e12 if per.get("root") and not root_inside else 0.0
+                stage_ms = per["eval"] + (0.0 if root_inside else per.get("root", 0.0))
+                lds_tbps = ks_l * 512 / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
+                occ = {}
+                for occ_file in ("r05_valu_occupancy.json", "r04_valu_occupancy.json", "r03_valu_occupancy.json", "r02_valu_occupancy.json"):
+                    try:                                      # VALU issue occupancy from the COMMITTED SQ counters (tools/valu_occupancy.py): a number
+                        occ = json.load(open(os.path.join(ROOT, "profiles", occ_file)))     # of another run of this kernel, not of this one
+                        occ["source"] = "profiles/%s: %s" % (occ_file, occ.get("source", ""))
+                        break
+                    except Exception:
+                        continue
+                mdelta = choice["eval"] == "eval_rows_mdelta_kernel"      # round 3's kernel for the same stage (experimental build + BGAMD_MFMA_DELTA=1)
+                ev = {"bound": "valu", "achieved": round(exec_tf, 3), "peak": PEAK_VALU_F32, "unit": "TFLOP/s",
+                      "frac": round(exec_tf / PEAK_VALU_F32, 4), "traffic": None, "avg_ms": round(per["eval"], 4),
+                      "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
+                      "kernel": choice["eval"], "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
+                      "flop_per_launch": int(ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE),
+                      "dense_equiv_tflops": round(eval_tf, 2), "dense_equiv_vs_f32_mfma_peak": round(eval_tf / peak, 3),
+                      # second resource: one 512-byte W1 column per (row, changed feature) out of LDS, ds_read_b128
+                      "lds_gather_GB_per_launch": round(ks_l * 512 / 1e9, 3), "lds_gather_TBps": round(lds_tbps, 2),
+                      "lds_peak_TBps": PEAK_LDS_TBPS, "lds_frac": round(lds_tbps / PEAK_LDS_TBPS, 4),
+                      "valu_issue_occupancy": None if mdelta else occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
+                      "valu_issue_occupancy_source": None if mdelta else occ.get("source"),
+                      "root_pass_kernel": choice["root"], "root_pass_on_second_stream": choice["root_on_second_stream"],
+                      "root_pass_avg_ms": None if root_inside else round(per.get("root", 0.0), 4),
+                      "root_pass_tflops": None if root_inside else round(root_tf, 2),
+                      "root_pass_frac_of_f32_mfma_peak": None if root_inside else round(root_tf / peak, 4),
+                      "value_net_stage_ms": round(stage_ms, 4),
+                      "value_net_stage_dense_equiv_tflops": round(u_l * FLOP_PER_ROW / (stage_ms * 1e-3) / 1e12, 2) if stage_ms else None,
+                      "note": "achieved = fp32 operations the kernel executes (128 FMAs per row and changed feature + 646 per row of "
+                              "sigmoids and output unit) / kernel time, peak = fp32 vector peak: the kernel runs on the VALUs (no MFMA, "
+                              "HBM at ~1.2 TB/s).  Its issue slots also carry what is not a flop -- LDS address arithmetic, list decoding, "
+                              "half-rate transcendentals (8-cycle issue) -- which is why the VALU issue occupancy from the SQ counters "
+                              "(valu_issue_occupancy, tools/valu_occupancy.py over profiles/) is far above frac."}
+            else:
+                exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
+                ev.update({"kernel": choice["eval"],
+                           "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
+                           "executed_frac_of_peak": round(exec_tf / peak, 4) if exec_tf else None,
+                           "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
+                           "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d); frac can exceed 1 because the "
+                                   "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"})
+            roofs = {
+                "eval": ev,
+                "leaves": {"kernel": "expand_all_kernel (doubles plies 2+3 and every leaf stage)" if merged else "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
+                           "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
+                "expand": {"kernel": "(inside expand_all_kernel)" if merged else "doubles_kernel (plies 2+3 of the doubles turns)", "bound": "hbm", "achieved": round(expand_gbs, 2),
+                           "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
+                           "avg_ms": round(per["expand"], 4)},
+            }
+            # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs; bench.py cannot
+            # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
+            for pmc_file in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
+                    for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_all_kernel" if merged else "expand_kernel<3>")):
+                        if key in pmc:
+                            roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
+                            roofs[name]["traffic_source"] = f"profiles/{pmc_file} (bytes per launch; a committed PMC pass of this kernel, not measured in this run)"
+                    break
+                except Exception:
+                    continue
+            dom = max(roofs, key=lambda k: roofs[k]["avg_ms"])
+            out["roofline"] = roofs[dom]
+            out["kernels"] = dict(roofs, apply_avg_ms=round(per["apply"], 4),
+                                  gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
+            if a.precision == "f32" and occ:
+                # the STEP's VALU issue occupancy: the three launches of a fused step, each one's occupancy weighted by its own duration in
+                # the committed SQ pass it comes from (a number of that pass, like valu_issue_occupancy above; not measured in this run)
+                parts = [occ.get(k) for k in ("expand_all_kernel", "eval_rows_delta_kernel", "boundary_kernel<true>")]
+                if all(parts):
+                    tt = sum(x["duration_us"] for x in parts)
+                    out["kernels"]["valu_issue_occupancy_step"] = round(sum(x["duration_us"] * x["valu_issue_occupancy"] for x in parts) / tt, 3)
+                    out["kernels"]["valu_issue_occupancy_step_source"] = occ.get("source")
+        if alt:
+            out["alt_modes"] = alt
+        if world > 1:
+            ms = [1e3 * t / a.steps for t in per_rank_s]
+            out["per_rank_ms_per_step"] = {"min": round(min(ms), 4), "max": round(max(ms), 4), "by_rank": [round(x, 4) for x in ms]}
+            out["dist_backend"] = a.dist_backend
+            out["launched_by"] = "bench.py launch_ranks" if os.environ.get("BENCH_LAUNCHED_BY") else "external launcher"
+        return out
+
+    out = build_line() if rank == 0 else None
+    # configs 4/5's per-GPU share, on EVERY rank (its replay's collectives are joined by all of them); outside the contract's bracket, and
+    # never at the cost of the line: an exception becomes {"error": ...}, and a watchdog thread ends a round that does not finish (a rank
+    # waiting in a collective another rank never joined) -- rank 0 prints the line it already has, every rank leaves with os._exit
     tr = None
     if a.training_round and a.games >= 4096:
+        finished = threading.Event()
+
+        def give_up():
+            if finished.is_set():
+                return
+            msg = f"training round did not finish within {a.training_round_timeout:.0f} s on rank {rank}: abandoned (the timed region above is complete)"
+            sys.stderr.write("bench.py: " + msg + "\n")
+            sys.stderr.flush()
+            if rank == 0:
+                out["training_round"] = {"error": msg}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(a.training_round_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             tr = training_round(bg, a.games, w, rank, world, a.dist_backend)
-        except Exception as e:                                  # extra information only: never costs the bench line
-            if world > 1:
-                raise                                           # ... unless ranks could be left waiting in a collective: fail loudly, the launcher reports
-            tr = {"error": repr(e)[:200]}
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            tr = {"error": repr(e)[:300]}
+        if use_dist:
+            dist.barrier()                                      # under the watchdog too: every rank is out of the round
+        finished.set()
+        dog.cancel()
     if rank != 0:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    u_step, c_step = distinct_ratio(env, prec, samples=1 if a.quick else 4)
-    # the other value-net modes on the same env (untimed region of the contract: extra information only)
-    alt = {}
-    if world == 1 and not a.quick:
-        for name, pm in (("f32", bg.F32), ("f32_dense", bg.F32_DENSE), ("f16x2", bg.F16X2), ("bf16", bg.BF16)):
-            if name == a.precision:
-                continue
-            env.run_greedy(10, precision=pm)
-            torch.cuda.synchronize()
-            s0, t1 = env.stats()["steps"], time.perf_counter()
-            env.run_greedy(100, precision=pm)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            alt[name] = {"env_steps_per_s": round((env.stats()["steps"] - s0) / dt, 1), "ms_per_step": round(10 * dt, 4)}
-        alt["note"] = ("f32_dense = dense v_mfma_f32_32x32x2_f32 chain over every afterstate (the r01 v6 headline path); "
-                       "f16x2 = W1 as f16 hi+lo (22 mantissa bits), exact products, fp32 accumulate: max |value - reference| 3e-7, "
-                       "inside the 1e-5 parity bound like f32; bf16 = speed mode outside it (1.2e-3)")
-    out = {
-        "metric": "self-play env steps/sec @65k concurrent games", "value": round(tot["steps"] / t_max, 1),
-        "unit": "env steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * t_max / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if a.precision == "f32_dense" else a.precision, "data": "synthetic",
-        "config": {"workload": "config3: 65 536 concurrent games per MI355X, greedy 198->128->1 value net "
-                               "(tdgammonNEW100k weights), auto-reset, Philox dice",
-                   "games_per_gpu": a.games, "burnin_steps": a.burnin, "parallelism": f"shard{world}",
-                   "raw_candidates_per_step": round(c_step, 2), "distinct_afterstates_per_step": round(u_step, 2),
-                   "staged_leaves_per_step": round(tot["candidates_raw"] / max(tot["steps"], 1), 2),
-                   "rows_evaluated_per_step": round(tot["rows_evaluated"] / max(tot["steps"], 1), 2),
-                   "games_finished": tot["games_finished"]},
-        # the timed region, as measured: every region is EXACTLY `steps` steps; more than one when the first was < 10 ms
-        "timed_regions": len(regions), "region_ms": {"min": round(1e3 * min(regions), 4), "median": round(1e3 * elapsed, 4),
-                                                     "max": round(1e3 * max(regions), 4)},
-        "source_hash": bg._capi.source_hash(), "library_build": bg._capi.load().bgamd_build_flags().decode(),
-    }
-    if kt:
-        nl = a.steps                                  # launches of the value-net kernel in the timed region (one per step)
-        # per-step GPU time of each kernel group: the value net as the mean of its bracketed launches in the timed
-        # region; the others from the short extra pass (a group may be bracketed more than once per step)
-        per = {k: (v["ms"] / (v["launches"] if k == "eval" else max(kt2["eval"]["launches"], 1)) if v["launches"] else 0.0)
-               for k, v in kt.items()}
-        rows_l, raw_l, steps_l = st["rows_evaluated"] / nl, st["candidates_raw"] / nl, st["steps"] / nl
-        fn_l, dn_l = st["leaf_parent_nodes"] / nl, st["doubles_inner_nodes"] / nl
-        # distinct afterstates per launch: U per step sampled on 4 x 2 048 positions after the run, never more than the
-        # rows the launch actually evaluated (every distinct afterstate is one of them)
-        u_l = min(steps_l * u_step, rows_l)
-        eval_tf = u_l * FLOP_PER_ROW / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
-        # algorithmic bytes: leaves = per leaf-parent 8 B node + 44 B state gather, per distinct
-        # afterstate 40 B out; expand = per game 44 B in + per node 8 B out/in; apply = 52 B in + 60 B out per game
-        merged = choice["expand"] == "expand_all_kernel"      # one launch for the doubles plies AND the leaf stage: both byte counts, one time
-        dbl_bytes = (fn_l + 2 * dn_l) * 8 + dn_l * 44
-        leaves_gbs = (fn_l * 52 + u_l * 40 + (dbl_bytes if merged else 0)) / (per["leaves"] * 1e-3) / 1e9 if per["leaves"] else 0.0
-        expand_gbs = (steps_l * 52 + dbl_bytes) / (per["expand"] * 1e-3) / 1e9 if per["expand"] and not merged else 0.0
-        ks_l = st.get("ksteps_executed", 0) / nl
-        peak = PEAK["f32" if a.precision == "f32_dense" else a.precision]
-        ev = {"bound": "mfma", "achieved": round(eval_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(eval_tf / peak, 4),
-              "traffic": None, "avg_ms": round(per["eval"], 4), "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l)}
-        if a.precision == "f32":
-            # The incremental evaluator executes no MFMA: its work is fp32 VALU arithmetic on W1 columns gathered from
-            # LDS, so THAT is the roof it is measured against: executed flop / kernel time over the fp32 vector peak.
-            # (The dense-equivalent figure -- SURVEY 8d's 50 944 flop per distinct afterstate -- stays as
-            # dense_equiv_tflops: it says how much faster than a perfect dense fp32 MFMA evaluation the stage is, and
-            # is not a fraction of anything.)  The per-game root pass is its own kernel (timed in slot "root").
-            exec_tf = (ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE) / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
-            root_inside = choice["root"] == "inside boundary_kernel<true>"     # no launch of its own: the boundary launch's time holds it
-            root_tf = steps_l * FLOP_PER_ROW / (per["root"] * 1e-3) / 1e12 if per.get("root") and not root_inside else 0.0
-            stage_ms = per["eval"] + (0.0 if root_inside else per.get("root", 0.0))
-            lds_tbps = ks_l * 512 / (per["eval"] * 1e-3) / 1e12 if per["eval"] else 0.0
-            occ = {}
-            for occ_file in ("r04_valu_occupancy.json", "r03_valu_occupancy.json", "r02_valu_occupancy.json"):
-                try:                                      # VALU issue occupancy from the COMMITTED SQ counters (tools/valu_occupancy.py): a number
-                    occ = json.load(open(os.path.join(ROOT, "profiles", occ_file)))     # of another run of this kernel, not of this one
-                    occ["source"] = "profiles/%s: %s" % (occ_file, occ.get("source", ""))
-                    break
-                except Exception:
-                    continue
-            mdelta = choice["eval"] == "eval_rows_mdelta_kernel"      # round 3's kernel for the same stage (experimental build + BGAMD_MFMA_DELTA=1)
-            ev = {"bound": "valu", "achieved": round(exec_tf, 3), "peak": PEAK_VALU_F32, "unit": "TFLOP/s",
-                  "frac": round(exec_tf / PEAK_VALU_F32, 4), "traffic": None, "avg_ms": round(per["eval"], 4),
-                  "rows_per_launch": int(rows_l), "distinct_per_launch": int(u_l),
-                  "kernel": choice["eval"], "w1_columns_per_row": round(ks_l / max(rows_l, 1), 3),
-                  "flop_per_launch": int(ks_l * FLOP_PER_COLUMN + rows_l * FLOP_PER_ROW_EPILOGUE),
-                  "dense_equiv_tflops": round(eval_tf, 2), "dense_equiv_vs_f32_mfma_peak": round(eval_tf / peak, 3),
-                  # second resource: one 512-byte W1 column per (row, changed feature) out of LDS, ds_read_b128
-                  "lds_gather_GB_per_launch": round(ks_l * 512 / 1e9, 3), "lds_gather_TBps": round(lds_tbps, 2),
-                  "lds_peak_TBps": PEAK_LDS_TBPS, "lds_frac": round(lds_tbps / PEAK_LDS_TBPS, 4),
-                  "valu_issue_occupancy": None if mdelta else occ.get("eval_rows_delta_kernel", {}).get("valu_issue_occupancy"),
-                  "valu_issue_occupancy_source": None if mdelta else occ.get("source"),
-                  "root_pass_kernel": choice["root"], "root_pass_on_second_stream": choice["root_on_second_stream"],
-                  "root_pass_avg_ms": None if root_inside else round(per.get("root", 0.0), 4),
-                  "root_pass_tflops": None if root_inside else round(root_tf, 2),
-                  "root_pass_frac_of_f32_mfma_peak": None if root_inside else round(root_tf / peak, 4),
-                  "value_net_stage_ms": round(stage_ms, 4),
-                  "value_net_stage_dense_equiv_tflops": round(u_l * FLOP_PER_ROW / (stage_ms * 1e-3) / 1e12, 2) if stage_ms else None,
-                  "note": "achieved = fp32 operations the kernel executes (128 FMAs per row and changed feature + 646 per row of "
-                          "sigmoids and output unit) / kernel time, peak = fp32 vector peak: the kernel runs on the VALUs (no MFMA, "
-                          "HBM at ~1.2 TB/s).  Its issue slots also carry what is not a flop -- LDS address arithmetic, list decoding, "
-                          "quarter-rate transcendentals -- which is why the VALU issue occupancy from the SQ counters "
-                          "(valu_issue_occupancy, tools/valu_occupancy.py over profiles/) is far above frac."}
-        else:
-            exec_tf = ks_l * 4 * 4096 / (per["eval"] * 1e-3) / 1e12 if per["eval"] and a.precision == "f32_dense" else None
-            ev.update({"kernel": choice["eval"],
-                       "executed_mfma_tflops": round(exec_tf, 2) if exec_tf else None,
-                       "executed_frac_of_peak": round(exec_tf / peak, 4) if exec_tf else None,
-                       "live_ksteps_frac": round(ks_l / (max(rows_l, 1) / 32 * 99), 4) if exec_tf else None,
-                       "note": "achieved = 50 944 flop x distinct afterstates / kernel time (SURVEY 8d); frac can exceed 1 because the "
-                               "kernel skips k-steps whose features are zero in every row of a tile -- executed_* is the MFMA work issued"})
-        roofs = {
-            "eval": ev,
-            "leaves": {"kernel": "expand_all_kernel (doubles plies 2+3 and every leaf stage)" if merged else "expand_kernel<LEAF>", "bound": "hbm", "achieved": round(leaves_gbs, 2), "peak": PEAK["hbm"],
-                       "unit": "GB/s", "frac": round(leaves_gbs / PEAK["hbm"], 5), "traffic": None, "avg_ms": round(per["leaves"], 4)},
-            "expand": {"kernel": "(inside expand_all_kernel)" if merged else "doubles_kernel (plies 2+3 of the doubles turns)", "bound": "hbm", "achieved": round(expand_gbs, 2),
-                       "peak": PEAK["hbm"], "unit": "GB/s", "frac": round(expand_gbs / PEAK["hbm"], 5), "traffic": None,
-                       "avg_ms": round(per["expand"], 4)},
-        }
-        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs; bench.py cannot
-        # collect counters itself) -- profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes
-        for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-                for name, key in (("eval", roofs["eval"]["kernel"]), ("leaves", "expand_all_kernel" if merged else "expand_kernel<3>")):
-                    if key in pmc:
-                        roofs[name]["traffic"] = round(pmc[key]["traffic_MB"] * 1e6)
-                        roofs[name]["traffic_source"] = f"profiles/{pmc_file} (bytes per launch; a committed PMC pass of this kernel, not measured in this run)"
-                break
-            except Exception:
-                continue
-        dom = max(roofs, key=lambda k: roofs[k]["avg_ms"])
-        out["roofline"] = roofs[dom]
-        out["kernels"] = dict(roofs, apply_avg_ms=round(per["apply"], 4),
-                              gpu_ms_per_step=round(per["eval"] + per.get("root", 0.0) + per["leaves"] + per["expand"] + per["apply"], 4))
-    if alt:
-        out["alt_modes"] = alt
     if tr is not None:
         out["training_round"] = tr
     if world == 1 and not a.no_cpu_baseline and not a.quick:
         out["cpu_baseline"] = cpu_baseline(w)
-    if world > 1:
-        ms = [1e3 * t / a.steps for t in per_rank_s]
-        out["per_rank_ms_per_step"] = {"min": round(min(ms), 4), "max": round(max(ms), 4), "by_rank": [round(x, 4) for x in ms]}
-        out["dist_backend"] = a.dist_backend
-        out["launched_by"] = "bench.py launch_ranks" if os.environ.get("BENCH_LAUNCHED_BY") else "external launcher"
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -4,6 +4,8 @@
   * eval_rows_d16_kernel (csrc/bg_eval_dense16.h, BGAMD_F16X2_RESIDENT=1) against the LDS-staged f16 x 2 kernel;
   * the LDS-staged root pass (BGAMD_ROOT_RESIDENT=0) against the resident one, bit for bit; the f32-MFMA root pass (BGAMD_ROOT_F32=1);
   * the learner's unfused matrix-pipe forward (BGAMD_TD_FUSED=0).
+  * (round 5) the launch structures of rounds 1-4 that lost their A/B, as bit-identity references of the default step: the root pass forced in / out of
+    the boundary launch or forked onto a second stream (BGAMD_ROOT_IN_BOUNDARY, BGAMD_OVERLAP), the expansion as two launches (BGAMD_EXPAND_MERGED=0).
 Marker gpu_experimental: `pytest -m gpu_experimental` (tools/round_check.sh runs it) builds libbgamd_experimental.so and loads it through
 BGAMD_LIB (tests/conftest.py); `-m gpu` and `-m "not gpu"` do not select these.  No parity test was dropped: what moved here still runs."""
 import os
@@ -13,9 +15,11 @@ import pytest
 
 from test_gpu_parity import _np
 from test_gpu_parity import test_incremental_value_net_equals_dense_chain as _dense_chain      # its third env: BGAMD_ROOT_F32=1
-from test_gpu_round2 import _streamed_replay_variant
+from test_gpu_round2 import _greedy_65536_sampled_lanes, _stream_modes_run_and_graph_capture, _streamed_replay_variant
 from test_gpu_round3 import _fixture_step
 from test_gpu_round3 import test_bar_positions_rows_vs_reference_values as _bar_rows
+from test_gpu_round4 import (_expansion_in_one_launch_odd_env_sizes, _expansion_in_one_launch_plays_the_same_games,
+                             _root_pass_inside_the_boundary_launch)
 
 pytestmark = pytest.mark.gpu_experimental
 
@@ -159,3 +163,30 @@ def test_f16x2_with_resident_weights_equals_the_lds_staged_f16x2_kernel(bg, weig
         e.run_greedy(30, precision=bg.F16X2)
     assert ((a.states() == b.states()).all(1)).float().mean().item() > 0.995
     assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
+
+
+# ---- round 5: the launch structures that lost their A/B are honoured by this build only ------------------------------------------------------
+
+def test_greedy_65536_sampled_lanes_vs_oracle_against_rounds_1_to_3_launch_structure(bg, O, weights):
+    a, b = _greedy_65536_sampled_lanes(bg, O, weights, twin_switches=("BGAMD_ROOT_IN_BOUNDARY=0", "BGAMD_OVERLAP=1"))
+    assert b.kernel_choice()["root_on_second_stream"] and not a.kernel_choice()["root_on_second_stream"]
+
+
+@pytest.mark.parametrize("mode", ["BGAMD_OVERLAP", "BGAMD_NO_OVERLAP"])
+def test_stream_modes_run_and_graph_capture(bg, weights, mode):
+    _stream_modes_run_and_graph_capture(bg, weights, mode)
+
+
+@pytest.mark.parametrize("n", [1000, 33000])
+def test_root_pass_forced_in_and_out_of_the_boundary_launch_is_bit_identical(bg, weights, monkeypatch, n):
+    _root_pass_inside_the_boundary_launch(bg, weights, monkeypatch, n, force=True)
+
+
+@pytest.mark.parametrize("n", [700, 33000])
+def test_expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, n):
+    _expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, n)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 1000, 4097, 24576])
+def test_expansion_in_one_launch_odd_env_sizes(bg, weights, monkeypatch, n):
+    _expansion_in_one_launch_odd_env_sizes(bg, weights, monkeypatch, n)

@@ -179,18 +179,21 @@ def test_delta_list_worst_case_and_overflow_flag(bg, O, weights):
 
 # ---- the headline configuration: 65 536 lanes, second-stream root pass, fused boundaries -------------------------------
 
-def test_greedy_65536_sampled_lanes_vs_oracle(bg, O, weights):
+def _greedy_65536_sampled_lanes(bg, O, weights, twin_switches=()):
     """At 65 536 lanes run_greedy fuses apply(t) + roots(t+1) + (round 4) the value net's root pass of step t + 1 into one launch, everything
-    on the caller's stream.  Sampled lanes are checked against the oracle after ONE step_greedy and after run_greedy(8); an env with rounds
-    1-3's launch structure (the root pass a launch of its own, forked onto the env's second stream: BGAMD_ROOT_IN_BOUNDARY=0 + BGAMD_OVERLAP=1)
-    must stay bit-identical to it throughout."""
+    on the caller's stream.  Sampled lanes are checked against the oracle after ONE step_greedy and after run_greedy(8) -- whose 8th step is
+    observable through a twin env that takes 7 steps of a run and then ONE separate step; the twin must stay bit-identical throughout.
+    twin_switches (experimental build, tests/test_gpu_experimental.py): the twin with rounds 1-3's launch structure (the root pass a launch
+    of its own, forked onto the env's second stream: BGAMD_ROOT_IN_BOUNDARY=0 + BGAMD_OVERLAP=1)."""
     n = 65536
     a = bg.VecGame(n, seed=777)
-    os.environ["BGAMD_ROOT_IN_BOUNDARY"] = "0"; os.environ["BGAMD_OVERLAP"] = "1"
+    for k in twin_switches:
+        os.environ[k.split("=")[0]] = k.split("=")[1]
     try:
         b = bg.VecGame(n, seed=777)
     finally:
-        del os.environ["BGAMD_ROOT_IN_BOUNDARY"]; del os.environ["BGAMD_OVERLAP"]
+        for k in twin_switches:
+            del os.environ[k.split("=")[0]]
     a.load_weights(weights); b.load_weights(weights)
     a.run_greedy(30); b.run_greedy(30)
     lanes = list(range(5, n, 257))                            # 255 lanes
@@ -216,10 +219,14 @@ def test_greedy_65536_sampled_lanes_vs_oracle(bg, O, weights):
     sa, sb = a.stats(), b.stats()
     assert sa["error_flags"] == 0 and sb["error_flags"] == 0
     assert all(sa[k] == sb[k] for k in ("steps", "games_finished", "p1_wins", "rows_evaluated"))
+    return a, b
 
 
-@pytest.mark.parametrize("mode", ["BGAMD_OVERLAP", "BGAMD_NO_OVERLAP"])
-def test_stream_modes_run_and_graph_capture(bg, weights, mode):
+def test_greedy_65536_sampled_lanes_vs_oracle(bg, O, weights):
+    _greedy_65536_sampled_lanes(bg, O, weights)
+
+
+def _stream_modes_run_and_graph_capture(bg, weights, mode):
     """The fork / join of the root pass (BGAMD_OVERLAP=1 forces it on a small env) under run_greedy(k > 1) and inside a
     captured HIP graph: bit-identical to single-stream stepping."""
     n = 3000

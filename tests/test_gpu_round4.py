@@ -277,15 +277,17 @@ def test_pooled_game_dropped_with_work_queued_on_a_side_stream(bg, weights):
 
 # ---- the root pass inside the boundary launch ----------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("n", [1000, 33000])
-def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monkeypatch, n):
+def _root_pass_inside_the_boundary_launch(bg, weights, monkeypatch, n, force):
     """Inside a run the root pass of step t + 1 runs in the boundary launch of step t (boundary_kernel<true>, bg_root_resident.h): against
-    the same run with the root pass as a launch of its own every step (BGAMD_ROOT_IN_BOUNDARY=0, rounds 1-3) and against single steps
-    (step_greedy: apply, roots and the stand-alone root pass) -- the same games, values and counters to the last bit, on lane counts that
-    leave partial tiles and partial workgroups, with exploration, across run boundaries and with the turn log on."""
-    monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "1")        # (the default from 24 576 lanes; below, the pass stays a launch of its own: forced here)
+    single steps (step_greedy: apply, roots and the stand-alone root pass) and -- force=True, experimental build: BGAMD_ROOT_IN_BOUNDARY=1 / 0
+    force either structure at any env size -- against the same run with the root pass as a launch of its own every step (rounds 1-3): the
+    same games, values and counters to the last bit, on lane counts that leave partial tiles and partial workgroups, with exploration,
+    across run boundaries and with the turn log on."""
+    if force:
+        monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "1")    # (the default from 24 576 lanes; below, the pass stays a launch of its own: forced here)
     a = bg.VecGame(n, seed=808)
-    monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "0")
+    if force:
+        monkeypatch.setenv("BGAMD_ROOT_IN_BOUNDARY", "0")
     b = bg.VecGame(n, seed=808)
     monkeypatch.delenv("BGAMD_ROOT_IN_BOUNDARY", raising=False)
     c = bg.VecGame(n, seed=808)
@@ -303,13 +305,19 @@ def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monk
     assert torch.equal(ta, tb)
     assert a.stats() == b.stats() == c.stats() and a.stats()["error_flags"] == 0
     assert a.kernel_choice()["root"] == "inside boundary_kernel<true>" and not a.kernel_choice()["root_on_second_stream"]
-    assert b.kernel_choice()["root"] == c.kernel_choice()["root"] == "root_hidden_resident_kernel"
+    assert c.kernel_choice()["root"] == "root_hidden_resident_kernel"
+    if force:
+        assert b.kernel_choice()["root"] == "root_hidden_resident_kernel"
 
 
-# ---- the expansion below the roots in one launch --------------------------------------------------------------------------------------
+def test_root_pass_inside_the_boundary_launch_is_bit_identical(bg, weights, monkeypatch):
+    """33 000 lanes: the default puts the pass inside the boundary launch (from 24 576 lanes); against single steps."""
+    _root_pass_inside_the_boundary_launch(bg, weights, monkeypatch, 33000, force=False)
 
-@pytest.mark.parametrize("n", [700, 33000])
-def test_expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, n):
+
+# ---- the expansion below the roots in one launch: against rounds 1-4's two launches (experimental build: tests/test_gpu_experimental.py) ------
+
+def _expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, n):
     """expand_all_kernel (the default): the doubles turns' plies 2 and 3 AND their leaf stage on the first workgroups of a launch whose
     other workgroups are the non-doubles leaf stage -- against doubles_kernel + expand_kernel<LEAF> (BGAMD_EXPAND_MERGED=0, rounds 1-4):
     the rows are the same rows in another order of the arena, so the games, the chosen values and sequences, the turn log and every
@@ -346,8 +354,7 @@ def test_expansion_in_one_launch_plays_the_same_games(bg, weights, monkeypatch, 
     assert a.kernel_choice()["expand"] == "expand_all_kernel" and b.kernel_choice()["expand"] == "doubles_kernel + expand_kernel<LEAF>"
 
 
-@pytest.mark.parametrize("n", [1, 63, 65, 1000, 4097, 24576])
-def test_expansion_in_one_launch_odd_env_sizes(bg, weights, monkeypatch, n):
+def _expansion_in_one_launch_odd_env_sizes(bg, weights, monkeypatch, n):
     """Env sizes around the launch's grid rules (one lane; a wave more or less; workgroup counts that do and do not divide by the four
     list parts; the size from which the root pass moves into the boundary launch): one launch against two, f32 and bf16, 45 steps with
     exploration -- the same games and counters."""

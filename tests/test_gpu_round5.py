@@ -196,11 +196,11 @@ def test_rows_past_the_steps_rows_read_as_zeros_and_incremental_rows_are_linear(
     v = env.evaluate_incremental(np.array(roots, dtype=np.int32), np.array(turns, dtype=np.int32), cands, np.array(ridx, dtype=np.int32))
     m = len(cands)
     st2 = torch.empty((m, 28), dtype=torch.int32, device="cuda")
-    v2 = torch.empty((m,), dtype=torch.float32, device="cuda")
-    rc = lib.bgamd_env_unique_rows_read(env._h, 0, m, ctypes.c_void_p(st2.data_ptr()), ctypes.c_void_p(v2.data_ptr()), s)
+    rc = lib.bgamd_env_unique_rows_read(env._h, 0, m, ctypes.c_void_p(st2.data_ptr()), None, s)
     assert rc == 0
     torch.cuda.synchronize()
-    assert np.array_equal(_np(st2), cands) and torch.equal(v2, v)
+    assert np.array_equal(_np(st2), cands)         # (its values go to the caller's buffer, not to the env's: only the rows are listed)
+    assert v.shape[0] == m and float(v.min()) > 0.0 and float(v.max()) < 1.0
 
 
 def test_ring_log_refuses_steps_that_break_its_game_table(bg, weights):

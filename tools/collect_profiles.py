@@ -29,6 +29,9 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
                        "hbm_read_MB_corrected_x2": round(2 * f[k] * 1024 / 1e6, 2), "hbm_write_MB": round(w.get(k, 0) * 1024 / 1e6, 2),
                        "traffic_MB": round((2 * f[k] + w.get(k, 0)) * 1024 / 1e6, 2)} for k in f}}
 json.dump(out, open(os.path.join(dst, tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
+tbm = os.path.join(src, "kernel_trace_by_mode.txt")   # tools/trace_by_mode.py: per-mode averages + the step timeline of the same rocprof run
+if os.path.exists(tbm):
+    shutil.copy(tbm, os.path.join(dst, f"{tag}_kernel_trace_by_mode.txt"))
 sq = os.path.join(src, "sq_counters.txt")            # tools/sq_counters.sh <tag>, when it was run for this tag
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, f"{tag}_sq_counters.txt"))
