@@ -271,7 +271,12 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
     the ranks between barriers, turns and updates the SUM: round_turns_per_s is the whole job's."""
     from backgammon_env.learner import ContinuousSelfPlay, DeviceTDLambdaLearner, play_round
     from backgammon_env.shard import shard_for_rank
-    multi = world > 1
+    # BENCH_FORCE_DIST=1 on one rank rehearses the multi-rank route end to end: process group, the learner's own RCCL communicator beside torch's, the
+    # in-library all-reduce of every training step (a world of one has nothing to move: what runs is every call the real thing makes)
+    forced = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1" and dist.is_initialized()
+    if forced:
+        os.environ["BGAMD_FORCE_COLLECTIVE"] = "1"
+    multi = world > 1 or forced
     group = dist.group.WORLD if multi else None
     cdev = torch.device("cuda", torch.cuda.current_device()) if (not multi or backend == "nccl") else torch.device("cpu")
     off, stride = shard_for_rank(rank, world, games)

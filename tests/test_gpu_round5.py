@@ -68,6 +68,30 @@ def test_bench_started_plainly_with_two_ranks():
           % (d["value"] / 1e6, pr["by_rank"], {k: v["round_turns_per_s"] for k, v in tr.items() if isinstance(v, dict)}, time.time() - t0))
 
 
+def test_bench_rccl_route_rehearsed_on_one_rank():
+    """BENCH_FORCE_DIST=1: the bench on ONE rank through everything the multi-GPU run does -- an RCCL process group (backend nccl), the census,
+    the barriers around the timed region, and a training round whose every training step is all-reduced by the LIBRARY on the learner's own
+    RCCL communicator (bgamd_td_replay_allreduce), lock-step, streamed, and from the learner's side stream and host thread beside an env at
+    play.  A world of one has nothing to move; what is exercised is every call more ranks make."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "16384", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    tr = d["training_round"]
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and "error" not in tr, tr
+    assert tr["collective"].startswith("in-library ncclAllReduce") and tr["collective_note"] is None and tr["replicas_identical"] is True
+    for k in ("lockstep_whole_round", "streamed_2048_slots", "continuous_window_84_steps", "continuous_window_84_steps_replay_beside_the_next_window"):
+        assert tr[k]["round_turns_per_s"] > 1e6, k
+    print("bench.py, RCCL route on one rank: %.1f M env steps/s; training round through the in-library all-reduce: %s"
+          % (d["value"] / 1e6, {k: v["round_turns_per_s"] for k, v in tr.items() if isinstance(v, dict)}))
+
+
 # ---- the launch structure the bench times, every lane against the oracle (VERDICT r4 item 5) --------------------------------------
 
 @pytest.mark.parametrize("n,mode,tol,ks", [(65536, "f32", 1e-5, (13, 39)), (32768, "bf16", 5e-3, (24,))])
