@@ -195,9 +195,11 @@ __device__ __forceinline__ void broot_load_weights(const uint4 *__restrict__ wl3
 #endif
 }
 
-// every thread of the workgroup calls it with ITS game's root row (32 bytes; zero for a lane past the env); g0 = the workgroup's first game
-__device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4 row0, uint4 row1, long long g0, long long n_games,
-                                                   const uint2 *__restrict__ lut, const float *__restrict__ b1, float *__restrict__ hidden)
+// The pass in two halves (round 5: the boundary launch collects its roots' list allocations between them).
+// boundary_root_stage: every thread of the workgroup calls it with ITS game's root row (32 bytes; zero for a lane past the env); g0 = the
+// workgroup's first game.  The rows go to LDS, every wave decodes its share of the tiles' A operands.  -> the workgroup's number of tiles.
+// Ends WITHOUT a barrier: the caller's next barrier (roots_collect has one) or boundary_root_compute's own orders the operands.
+__device__ __forceinline__ int boundary_root_stage(uint4 row0, uint4 row1, long long g0, long long n_games, const uint2 *__restrict__ lut)
 {
     extern __shared__ uint4 sBR[];
     uint4 *sX = sBR;                                                      // [8 tiles][13][64]
@@ -210,8 +212,6 @@ __device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4
     }
     const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
-    constexpr float NL2E = -1.44269504088896340736f;
-    const float bb = b1[32 * c + r];
     long long left = n_games - g0;
     const int n_tiles = left <= 0 ? 0 : (int)((left < BROOT_GPW ? left : BROOT_GPW) + 31) >> 5;     // workgroup-uniform
     __syncthreads();
@@ -239,6 +239,18 @@ __device__ __forceinline__ void boundary_root_pass(const BRootWeights &wf, uint4
             dst[12 * 64] = h ? make_uint4(0, 0, 0, 0) : make_uint4(t0 | (t1 << 16), bar1 | (bar2 << 16), off1 | (off2 << 16), 0u);
         }
     }
+    return n_tiles;
+}
+
+__device__ __forceinline__ void boundary_root_compute(const BRootWeights &wf, int n_tiles, long long g0, long long n_games,
+                                                      const float *__restrict__ b1, float *__restrict__ hidden)
+{
+    extern __shared__ uint4 sBR[];
+    uint4 *sX = sBR;
+    const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    constexpr float NL2E = -1.44269504088896340736f;
+    const float bb = b1[32 * c + r];
     __syncthreads();
     union WF { uint4 u; root_vec8 v; };
     // two tiles per iteration: two independent accumulator chains and twice the LDS reads in flight -- with ONE wave per SIMD nothing else

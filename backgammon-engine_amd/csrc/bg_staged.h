@@ -31,6 +31,15 @@ __host__ __device__ __forceinline__ uint32_t key_child(uint32_t k, int o)
 
 struct Node { uint32_t game, key; };
 
+// A value every lane of the wave holds alike (a total or a list position read back from LDS): v_readfirstlane tells the compiler so, and the value
+// lives in SGPRs from there on.  Round 5: the expansion kernels are built AT their register cap (128 VGPRs, 4 waves per SIMD) and were spilling
+// block-uniform totals and bases that sat in vector registers for whole phases.
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long x)
+{
+    return ((unsigned long long)uniform_u32((uint32_t)(x >> 32)) << 32) | (unsigned long long)uniform_u32((uint32_t)x);
+}
+
 template <bool LDS_ONLY>
 __device__ __forceinline__ void block_barrier()
 {
@@ -61,7 +70,7 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, 
         if (w < wv) base += x;
         tot += x;
     }
-    *total = tot;
+    *total = uniform_u32(tot);
     return base + incl - v;
 }
 
@@ -72,7 +81,7 @@ __device__ __forceinline__ unsigned long long block_alloc(unsigned long long *to
     if (LEAD_SYNC) block_barrier<LDS_ONLY>();
     if (threadIdx.x == 0) *s_slot = total ? atomicAdd(top, (unsigned long long)total) : 0ull;
     block_barrier<LDS_ONLY>();
-    return *s_slot;
+    return uniform_u64(*s_slot);
 }
 
 // two lists at once, both atomics in flight together: the block waits for one round trip instead of two.  (Inline: the
@@ -93,7 +102,18 @@ __device__ __forceinline__ void block_alloc2(unsigned long long *topA, uint32_t 
         s_slot[0] = a; s_slot[1] = b;
     }
     __syncthreads();
-    baseA = s_slot[0]; baseB = s_slot[1];
+    baseA = uniform_u64(s_slot[0]); baseB = uniform_u64(s_slot[1]);
+}
+
+// A RETURNING 64-bit add whose result the COMPILER tracks: its s_waitcnt goes where the result is first used, not where the atomic is issued, so
+// the ~1.1 us round trip of a block allocation can run under work that does not need the base yet (round 5: the first successor of every lane of
+// an expansion phase; the staging of the root pass in the boundary launch).  The opaque zero offset makes the pointer divergent for the compiler:
+// its atomic optimiser then leaves the instruction alone (it would read the result back through v_readfirstlane on the spot).
+__device__ __forceinline__ unsigned long long atomic_add_deferred(unsigned long long *top, unsigned long long v)
+{
+    uint32_t zero = 0;
+    asm volatile("" : "+v"(zero));
+    return __hip_atomic_fetch_add(top + zero, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct StagedView {

@@ -50,13 +50,24 @@ __device__ __forceinline__ void flag_overflow(const EnvView &e)
 #endif
 constexpr int LANE_NT = BG_LANE_NT;
 
+// The roots of a step in two halves (round 5): roots_issue does everything that needs no list position -- the roll, the ply-1 moves, the scan, the
+// lane's root row, turn log and dice -- and ISSUES the workgroup's two list allocations (returning atomics, thread 0); roots_collect waits for
+// them and writes the nodes.  A caller with work of its own in between (the boundary launch: the staging of the root pass) hides the
+// allocation's round trip under it; roots_body is the two back to back.
+struct RootsPending {
+    uint32_t ma, mb, offF, offD, totF, totD;
+    uint32_t game;
+    int sh;
+    bool live, dbl;
+    unsigned long long r0, r1;                             // thread 0: the two bases on their way
+};
+
 // pre (optional): the lane's state handed over in registers by the apply of the turn before (boundary_kernel)
 // row_out (optional, [2]): the lane's root row as written to sv.root_rows (zero for a lane past the env), for a caller that goes on with it
-__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr,
-                                           uint4 *row_out = nullptr)
+__device__ __forceinline__ void roots_issue(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre, uint4 *row_out,
+                                            RootsPending &P)
 {
     __shared__ uint32_t s_wave[LANE_NT / 64];
-    __shared__ unsigned long long s_slot[2];
     LaneCtx c;
     if (pre) {
 #pragma unroll
@@ -80,31 +91,17 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
     // in flight together
     uint32_t totFD;
     const uint32_t offFD = block_scan_256<LANE_NT / 64>(nF | (nD << 16), &totFD, s_wave);
-    const uint32_t totF = totFD & 0xFFFFu, totD = totFD >> 16;
-    uint32_t offF = offFD & 0xFFFFu, offD = offFD >> 16;
-    unsigned long long baseF, baseD;
-    // (sharded lists: this workgroup's lists are number blockIdx.x % shards; bases below are absolute positions in sv.f / sv.d1)
-    const int sh = sv.shards > 1 ? (int)(blockIdx.x % (unsigned)sv.shards) : 0;
-    const unsigned long long capF = (unsigned long long)(sv.cap_f / sv.shards), capD = (unsigned long long)(sv.cap_d1 / sv.shards);
-    block_alloc2(&sv.tops[f_counter(sh)], totF, &sv.tops[d1_counter(sh)], totD, s_slot, baseF, baseD);
-    const bool okF = baseF + totF <= capF, okD = baseD + totD <= capD;
-    baseF += (unsigned long long)sh * capF;
-    baseD += (unsigned long long)sh * capD;
-    if (!okF || !okD) flag_overflow(e);
+    P.totF = totFD & 0xFFFFu; P.totD = totFD >> 16;
+    P.offF = offFD & 0xFFFFu; P.offD = offFD >> 16;
+    // (sharded lists: this workgroup's lists are number blockIdx.x % shards)
+    P.sh = sv.shards > 1 ? (int)(blockIdx.x % (unsigned)sv.shards) : 0;
+    P.r0 = P.r1 = 0;
+    if (threadIdx.x == 0) {                                 // both issued unconditionally: the totals are almost never zero
+        P.r0 = atomic_add_deferred(&sv.tops[f_counter(P.sh)], (unsigned long long)P.totF);
+        P.r1 = atomic_add_deferred(&sv.tops[d1_counter(P.sh)], (unsigned long long)P.totD);
+    }
+    P.ma = ma; P.mb = mb; P.live = c.live; P.dbl = dbl; P.game = (uint32_t)g;
     if (c.live) {
-        const uint32_t gg = (uint32_t)g;
-        if (dbl) {
-            if (ma == 0) { if (okF) sv.f[baseF + offF] = Node{gg, 0u}; }
-            else if (okD) {
-                uint32_t m = ma;
-                while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.d1[baseD + offD++] = Node{gg, key_child(0u, o)}; }
-            }
-        } else if (okF) {
-            uint32_t m = ma;
-            while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.f[baseF + offF++] = Node{gg, key_child(0u, o)}; }
-            m = mb;
-            while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.f[baseF + offF++] = Node{gg, key_child(1u << KEY_PASS_SHIFT, o)}; }
-        }
         if (flags & BGAMD_ROLL) e.meta[g] = meta_pack(c.turn, c.d1, c.d2, false);
         const long long lrow = e.traj_ring ? e.log_slot : (long long)c.ply;      // ring log: by env step; else by the lane's ply
         if (e.traj && lrow < e.traj_plies) {                    // trajectory log: 32 B per turn instead of 792 B
@@ -121,6 +118,43 @@ __device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &s
         sv.root_rows[2 * g + 1] = r1;
         if (row_out) { row_out[0] = r0; row_out[1] = r1; }
     }
+}
+
+__device__ __forceinline__ void roots_collect(const EnvView &e, const StagedView &sv, RootsPending &P)
+{
+    __shared__ unsigned long long s_slot[2];
+    if (threadIdx.x == 0) { s_slot[0] = P.r0; s_slot[1] = P.r1; }      // (the compiler's wait for the two results sits here)
+    __syncthreads();
+    unsigned long long baseF = uniform_u64(s_slot[0]), baseD = uniform_u64(s_slot[1]);
+    const unsigned long long capF = (unsigned long long)(sv.cap_f / sv.shards), capD = (unsigned long long)(sv.cap_d1 / sv.shards);
+    const bool okF = baseF + P.totF <= capF, okD = baseD + P.totD <= capD;
+    baseF += (unsigned long long)P.sh * capF;               // absolute positions in sv.f / sv.d1
+    baseD += (unsigned long long)P.sh * capD;
+    if (!okF || !okD) flag_overflow(e);
+    if (P.live) {
+        const uint32_t gg = P.game;
+        uint32_t offF = P.offF, offD = P.offD;
+        if (P.dbl) {
+            if (P.ma == 0) { if (okF) sv.f[baseF + offF] = Node{gg, 0u}; }
+            else if (okD) {
+                uint32_t m = P.ma;
+                while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.d1[baseD + offD++] = Node{gg, key_child(0u, o)}; }
+            }
+        } else if (okF) {
+            uint32_t m = P.ma;
+            while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.f[baseF + offF++] = Node{gg, key_child(0u, o)}; }
+            m = P.mb;
+            while (m) { const int o = __ffs(m) - 1; m &= m - 1; sv.f[baseF + offF++] = Node{gg, key_child(1u << KEY_PASS_SHIFT, o)}; }
+        }
+    }
+}
+
+__device__ __forceinline__ void roots_body(const EnvView &e, const StagedView &sv, int flags, long long g, const LaneCtx *pre = nullptr,
+                                           uint4 *row_out = nullptr)
+{
+    RootsPending P;
+    roots_issue(e, sv, flags, g, pre, row_out, P);
+    roots_collect(e, sv, P);
 }
 
 __global__ __launch_bounds__(LANE_NT) void roots_kernel(EnvView e, StagedView sv, int flags)
@@ -593,7 +627,12 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
     const unsigned long long xall_t0 = wall_clock64();
     if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) e.values[e.cap - 1 - 4096 - (long long)blockIdx.x * 8 - k] = 0.0f;
 #endif
-    unsigned long long staged_total = 0, fnodes = 0, dnodes = 0;
+    // (the launch's three statistics as 32-bit per-thread accumulators: as 64-bit ones they held six VGPRs for the whole launch in a kernel built at its
+    //  register cap; a workgroup stages a few thousand rows at most)
+    uint32_t acc_staged = 0, acc_fnodes = 0, acc_dnodes = 0;
+    auto add_staged = [&](unsigned long long v) { acc_staged += (uint32_t)v; };
+    auto add_fnodes = [&](unsigned long long v) { acc_fnodes += (uint32_t)v; };
+    auto add_dnodes = [&](unsigned long long v) { acc_dnodes += (uint32_t)v; };
     // the first n_dbl workgroups take the doubles turns, the others the non-doubles leaf stage.  (Every workgroup taking a share of both
     // kinds -- the same mix everywhere -- was measured too: 32-37 us against 29.4: the two kinds overlap when they share a CU as
     // different workgroups, and follow one another inside one.)
@@ -608,7 +647,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
         unsigned long long n_in = sv.tops[d1_counter(shd)];
         if (n_in > capD) n_in = capD;
         const unsigned long long d_first = (unsigned long long)blockIdx.x / (unsigned)sv.shards, d_stride = (unsigned long long)n_dbl / (unsigned)sv.shards;
-        if (d_first == 0) dnodes = n_in;
+        if (d_first == 0) add_dnodes(n_in);
         unsigned long long NPB = (n_in + d_stride - 1) / d_stride;
         NPB = NPB < 1 ? 1 : (NPB > (unsigned long long)dbl_npb ? (unsigned long long)dbl_npb : NPB);           // (dbl_npb <= NT)
         // leaf stage over a range of the workgroup's own F2 entries (successors that did not fit the register hand-off)
@@ -620,7 +659,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
                 NodeIn x4;
                 node_fetch(e, sv.f2, threadIdx.x < n4 ? (long long)(base + c4 + threadIdx.x) : -1ll, x4);
                 expand_phase<MODE_LEAF, NT>(e, sv, x4, NT, &base4, &total4, lp, L, nullptr, nullptr, nullptr, true);
-                staged_total += total4;
+                add_staged(total4);
             }
         };
         // (a workgroup takes a CONTIGUOUS run of the list: every W-th node instead -- a game's ply-1 nodes on different workgroups, whose
@@ -636,14 +675,14 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
             ChainNode n3, n4;
             node_fetch(e, d1_list, threadIdx.x < cnt ? (long long)(first + threadIdx.x) : -1ll, x2);
             expand_phase<MODE_PLY2, NT, true, true>(e, sv, x2, (int)NPB, &over2_base, &over2, lp, L, &stuck2, &n3, &all2);
-            dnodes += all2;
-            fnodes += stuck2;
-            staged_total += stuck2;
+            add_dnodes(all2);
+            add_fnodes(stuck2);
+            add_staged(stuck2);
             // ... ply 3 on those, the same way, then their leaf stage
             expand_phase_chained<MODE_PLY3, NT>(e, sv, n3, &over3_base, &over3, lp, L, &n4, &all3);
-            fnodes += all3;
+            add_fnodes(all3);
             expand_phase_chained<MODE_LEAF, NT>(e, sv, n4, &base4, &total4, lp, L, nullptr, nullptr);
-            staged_total += total4;
+            add_staged(total4);
             if (over2 | over3) __syncthreads();                // (block-uniform) listed successors: their stores have to have landed
             leaf_range(over3_base, over3);                     // ply-3 successors past the first NT: through F2
             for (uint32_t c = 0; c < over2; c += NT) {          // ply-2 successors past the first NT: through D2, one ply per phase
@@ -653,7 +692,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
                 NodeIn x3;
                 node_fetch(e, sv.d2, threadIdx.x < n3c ? (long long)(over2_base + c + threadIdx.x) : -1ll, x3);
                 expand_phase<MODE_PLY3, NT>(e, sv, x3, NT, &base3, &total3, lp, L);
-                fnodes += total3;
+                add_fnodes(total3);
                 leaf_range(base3, total3);
             }
         }
@@ -666,7 +705,7 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
         unsigned long long n_in = sv.tops[f_counter(shf)];
         if (n_in > capF) n_in = capF;
         const unsigned long long l_first = lw / (unsigned)sv.shards, l_stride = (unsigned long long)(gridDim.x - n_dbl) / (unsigned)sv.shards;
-        if (l_first == 0) fnodes += n_in;
+        if (l_first == 0) add_fnodes(n_in);
         // a contiguous share per workgroup, cut into equal phases of at most NT parents (645 parents are 2 x 323, not 512 + 133: a phase
         // costs its latencies whatever it holds, and equal shares end together)
         const unsigned long long share = (n_in + l_stride - 1) / l_stride;
@@ -685,11 +724,12 @@ __global__ __launch_bounds__(XALL_NT, 4) void expand_all_kernel(EnvView e, Stage
             unsigned long long base;
             uint32_t total;
             expand_phase<MODE_LEAF, NT>(e, sv, cur, (int)per, &base, &total, leaf_parents_shared(sv), L);
-            staged_total += total;
+            add_staged(total);
             cur = nxt;
         }
     }
     if (threadIdx.x == 0) {
+        const unsigned long long staged_total = acc_staged, fnodes = acc_fnodes, dnodes = acc_dnodes;
         if (staged_total) atomicAdd(&e.counters[C_CAND_RAW], staged_total);
         if (fnodes) atomicAdd(&e.counters[C_FNODES], fnodes);
         if (dnodes) atomicAdd(&e.counters[C_DNODES], dnodes);
@@ -797,6 +837,17 @@ __global__ __launch_bounds__(LANE_NT, 2) void boundary_kernel(EnvView e, StagedV
     uint4 row[2];
     BRootWeights wf;
     if (ROOT) broot_load_weights(wl3, wf);
-    roots_body(e, sv_next, flags, g, &next, ROOT ? row : nullptr);
-    if (ROOT) boundary_root_pass(wf, row[0], row[1], (long long)blockIdx.x * GPW, e.n, lut, b1, sv_next.root_hidden);
+    RootsPending P;
+    roots_issue(e, sv_next, flags, g, &next, ROOT ? row : nullptr, P);
+    // (round 5) the roots' two list allocations are in flight while the root pass stages its A operands: their round trip used to stand
+    // in front of it (-DBG_ALLOC_DEFERRED=0: collect first, as rounds 1-4 did)
+#if defined(BG_ALLOC_DEFERRED) && !BG_ALLOC_DEFERRED
+    roots_collect(e, sv_next, P);
+#endif
+    int n_tiles = 0;
+    if (ROOT) n_tiles = boundary_root_stage(row[0], row[1], (long long)blockIdx.x * GPW, e.n, lut);
+#if !defined(BG_ALLOC_DEFERRED) || BG_ALLOC_DEFERRED
+    roots_collect(e, sv_next, P);
+#endif
+    if (ROOT) boundary_root_compute(wf, n_tiles, (long long)blockIdx.x * GPW, e.n, b1, sv_next.root_hidden);
 }

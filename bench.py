@@ -257,7 +257,7 @@ def cpu_baseline(weights, budget_s=10.0):
     return out
 
 
-def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
+def training_round(bg, games, w, rank=0, world=1, backend="nccl", rehearsal=False):
     """Extra information (outside the timed region of the contract): one training round of configs 4/5's per-GPU share -- self-play
     of `games` games per rank with the turn log from a frozen snapshot (train.py:527-547), then the TD(lambda) replay of the round on the
     HIP learner kernels (bgamd_td_*): lock-step over the whole round, and streamed through 2 048 slots (the configuration the
@@ -268,7 +268,10 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
     library on the learner's own RCCL communicator (DeviceTDLambdaLearner.init_collective -> bgamd_td_replay_allreduce) with backend nccl,
     through torch.distributed with the gloo rehearsal backend (ranks sharing a GPU cannot form an RCCL communicator) -- and the replicas'
     weights are compared bit for bit at the end of every phase (MIN == MAX of a 64-bit checksum over the ranks).  Times are the MAX over
-    the ranks between barriers, turns and updates the SUM: round_turns_per_s is the whole job's."""
+    the ranks between barriers, turns and updates the SUM: round_turns_per_s is the whole job's.
+    rehearsal (ranks SHARING a GPU over gloo): the same route once through -- one pass per replay, three windows per loop -- because processes that
+    share a GPU take turns on it: an all-reduce of a device tensor then costs a scheduling quantum (1 ms with two processes on the card, ~35 ms with
+    three), and the numbers measure that, not the learner."""
     from backgammon_env.learner import ContinuousSelfPlay, DeviceTDLambdaLearner, play_round
     from backgammon_env.shard import shard_for_rank
     # BENCH_FORCE_DIST=1 on one rank rehearses the multi-rank route end to end: process group, the learner's own RCCL communicator beside torch's, the
@@ -318,14 +321,15 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
         return reduce(cs, dist.ReduceOp.MIN if multi else None) == reduce(cs, dist.ReduceOp.MAX if multi else None), cs
 
     L = learner(games)
-    for _ in range(2):
+    passes, n_win, first_win = (1, 3, 1) if rehearsal else (2, 8, 4)
+    for _ in range(passes):
         (rows, lengths, won), dt_play = timed(lambda: play_round(env, max_plies=600, epsilon=0.05))
     turns = reduce(int(lengths.sum().item()), dist.ReduceOp.SUM if multi else None)
     out = {"games": games * world, "games_per_rank": games, "ranks": world, "turns": turns, "selfplay_with_turn_log_ms": round(1e3 * dt_play, 2),
            "collective": None}
     ident = True
     for name, kw in (("lockstep_whole_round", {}), ("streamed_2048_slots", {"slots": 2048})):
-        for _ in range(2):
+        for _ in range(passes):
             L.set_weights(w)
             (sq, cnt), dt = timed(lambda: L.replay_rows(rows, lengths, won, group=group,
                                                         batch_scale=24.0 / (world * (kw.get("slots") or games)), **kw))
@@ -352,7 +356,7 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
                 res["r"] = L.replay_games(sp.rows, *tab, slots=2048, group=group, batch_scale=24.0 / (world * 2048))
             side.synchronize()
         pending = None
-        for r in range(8):
+        for r in range(n_win):
             if multi:
                 dist.barrier(group)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -369,14 +373,14 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
             else:
                 replay(tab)
             torch.cuda.synchronize()
-            if r >= 4:
+            if r >= first_win:
                 times.append(time.perf_counter() - t0)
         ms = reduce(1e3 * float(np.median(times)), dist.ReduceOp.MAX if multi else None)
         trn = reduce(int(res["r"][1]), dist.ReduceOp.SUM if multi else None)
         same, cs = replicas_identical(L)
         ident = ident and same
         out["continuous_window_84_steps" + ("_replay_beside_the_next_window" if pipe else "")] = {
-            "window_ms": round(ms, 2), "selfplay_ms": round(1e3 * float(np.median(t_play[4:])), 2) if not pipe else None,
+            "window_ms": round(ms, 2), "selfplay_ms": round(1e3 * float(np.median(t_play[first_win:])), 2) if not pipe else None,
             "turns_replayed": trn, "round_turns_per_s": round(trn / ms * 1e3, 1), "weights_checksum": "%016x" % (cs & (2 ** 64 - 1))}
         sp.close()
     out["replicas_identical"] = bool(ident)
@@ -384,6 +388,8 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl"):
                          else "torch.distributed all_reduce over %s%s" % (backend, " (rehearsal)" if backend != "nccl" else "")) + \
                         ("" if not multi else ", one per training step")
     out["collective_note"] = coll["note"]
+    if rehearsal:
+        out["rehearsal"] = "ranks share a GPU: one pass per replay, three windows per loop; times are scheduling quanta, not the learner's"
     del L, env
     return out
 
@@ -673,20 +679,28 @@ def main(argv=None):
         dog = threading.Timer(a.training_round_timeout, give_up)
         dog.daemon = True
         dog.start()
+        # (ranks that share a GPU -- the gloo rehearsal -- take turns on it and pay a host round trip per all-reduce: the rehearsal exercises the
+        #  route on a smaller round; a measurement it is not)
+        rehearsal = world > 1 and a.dist_backend != "nccl"
+        tr_games = min(a.games, 4096) if rehearsal else a.games
         try:
-            tr = training_round(bg, a.games, w, rank, world, a.dist_backend)
+            tr = training_round(bg, tr_games, w, rank, world, a.dist_backend, rehearsal=rehearsal)
         except Exception as e:
             import traceback
             traceback.print_exc()
             tr = {"error": repr(e)[:300]}
-        if use_dist:
+        if use_dist and "error" not in tr:
             dist.barrier()                                      # under the watchdog too: every rank is out of the round
         finished.set()
         dog.cancel()
-    if rank != 0:
-        if use_dist:
+    tr_failed = tr is not None and "error" in tr                # (the process group may be gone with the rank that failed: no more collectives)
+
+    def leave():
+        if use_dist and not tr_failed:
             dist.barrier()
             dist.destroy_process_group()
+    if rank != 0:
+        leave()
         return
 
     if tr is not None:
@@ -694,9 +708,7 @@ def main(argv=None):
     if world == 1 and not a.no_cpu_baseline and not a.quick:
         out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    leave()
 
 
 if __name__ == "__main__":

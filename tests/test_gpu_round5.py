@@ -59,10 +59,11 @@ def test_bench_started_plainly_with_two_ranks():
     assert abs(d["value"] - 2 * 32768 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-3 * d["value"]
     assert d["value"] > 5e7 and "cpu_baseline" not in d and "roofline" in d
     tr = d["training_round"]
-    assert "error" not in tr and tr["ranks"] == 2 and tr["games"] == 65536 and tr["replicas_identical"] is True
-    assert "all_reduce" in tr["collective"] and tr["turns"] > 4e6
+    # (ranks sharing a GPU rehearse the training round on 4 096 games each, once through: the route, not a measurement)
+    assert "error" not in tr and tr["ranks"] == 2 and tr["games"] == 8192 and tr["replicas_identical"] is True and "rehearsal" in tr
+    assert "all_reduce" in tr["collective"] and tr["turns"] > 4e5
     for k in ("lockstep_whole_round", "streamed_2048_slots", "continuous_window_84_steps", "continuous_window_84_steps_replay_beside_the_next_window"):
-        assert tr[k]["round_turns_per_s"] > 1e6, k
+        assert tr[k]["round_turns_per_s"] > 1e4, k
     assert tr["lockstep_whole_round"]["weights_checksum"] != tr["streamed_2048_slots"]["weights_checksum"]
     print("bench.py --gpus 2 (gloo, two ranks on one GPU), started plainly: %.1f M env steps/s, per-rank ms/step %s; training round: %s; %.0f s"
           % (d["value"] / 1e6, pr["by_rank"], {k: v["round_turns_per_s"] for k, v in tr.items() if isinstance(v, dict)}, time.time() - t0))
