@@ -392,6 +392,10 @@ __device__ __forceinline__ void expand_phase_core(const EnvView &e, const Staged
     }
     (void)off;
     BG_PSTAMP(1);                          // scan + successor table
+    // (Round 5, measured and not kept: the phase's allocations issued right after the scan and collected after every lane has built its FIRST successor,
+    //  the round trip of thread 0's returning atomics under that work -- atomic_add_deferred, bg_staged.h.  The successor held across the barrier costs
+    //  registers the kernel does not have: 46 spilled VGPRs and 33.3 us against 28.5; with the block-uniform values in SGPRs 19 and 27.2 against 27.9 us at
+    //  65 536 lanes, 21.9 against 21.0 us at 32 768: profiles/r05_ab_expansion_registers.txt.)
     // what goes through the output list: everything, or (CHAIN) the successors past the first NT
     const uint32_t listed = CHAIN ? (total > (uint32_t)NT ? total - (uint32_t)NT : 0u) : total;
     const uint32_t q0 = CHAIN ? (uint32_t)NT : 0u;             // first successor that does
