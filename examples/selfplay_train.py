@@ -147,7 +147,10 @@ def main():
     ap.add_argument("--scale-warmup", type=float, default=0.0, help="first round's --scale-games (doubling every round up to --scale-games): "
                     "the summed update of a large step overshoots while the net is random and every game pushes the same way (0 = no warm-up)")
     ap.add_argument("--arena", type=int, default=1024, help="lanes of the evaluation arena (2 games per lane, sides alternated)")
-    ap.add_argument("--max-plies", type=int, default=600)
+    ap.add_argument("--max-plies", type=int, default=400, help="turn log depth of a classic round: a game that is not over by then is not replayed.  400 is what the "
+                    "quality gate runs with (tools/quality_r04.sh); round 5 found that with 600 the long games of the FIRST rounds from a random net -- hundreds of "
+                    "turns of noise each, summed into one update -- push every loop, the classic one included, into the 'short games' attractor "
+                    "(1.2 %% against tdgammonNEW100k instead of 53 %%: profiles/r05_training_quality.txt)")
     ap.add_argument("--lam", type=float, default=None, help="fixed lambda (default: the reference schedule, model.py:69-73)")
     ap.add_argument("--schedule-div", type=int, default=1, help="the reference's alpha / lambda schedule is a function of the episode count "
                     "(model.py:69-73, written for runs of ~1e5 episodes); it is evaluated at games_done // this")
