@@ -42,3 +42,28 @@ def test_committed_bench_line_roofline_is_a_fraction():
     assert avg_ns and abs(avg_ns * 1e-6 - r["avg_ms"]) < 0.1 * r["avg_ms"]
     c = d["cpu_baseline"]
     assert c["host"]["cpu_model"] and c["all_cores"]["cores"] == c["host"]["usable_cores"] and c["reference_engine"]["value"]
+
+
+def test_round5_evidence_is_consistent():
+    """The committed round-5 evidence hangs together: the bench line is a fraction of its roof; the trace summary of the SAME rocprof run
+    (tools/trace_by_mode.py) puts the value net's timed-region average within 10 % of the bench's HIP-event time and the three launches'
+    sum within 5 % of the step period; the occupancy file reproduces from its counter summary; the step-level figure is the duration-
+    weighted mean of the three launches."""
+    import re
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_v61_bench_f32.json")))
+    r = d["roofline"]
+    assert r["bound"] == "valu" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["ranks_seen"] == 1 and d["training_round"]["replicas_identical"] and "error" not in d["training_round"]
+    txt = open(os.path.join(ROOT, "profiles", "r05_v61_kernel_trace_by_mode.txt")).read()
+    timed = txt[txt.index("the TIMED REGION"):]
+    avg = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+calls\s+\d+\s+mean\s+([\d.]+) us", timed, re.M)}
+    assert abs(avg["eval_rows_delta_kernel"] * 1e-3 - r["avg_ms"]) < 0.1 * r["avg_ms"]
+    period = float(re.search(r"step period: mean ([\d.]+)", timed).group(1))
+    busy = avg["expand_all_kernel"] + avg["eval_rows_delta_kernel"] + avg["boundary_kernel<true>"]
+    assert abs(busy - period) < 0.05 * period and abs(period * 1e-3 - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    occ = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_occupancy.json")))
+    parts = [occ[k] for k in ("expand_all_kernel", "eval_rows_delta_kernel", "boundary_kernel<true>")]
+    step = sum(x["duration_us"] * x["valu_issue_occupancy"] for x in parts) / sum(x["duration_us"] for x in parts)
+    assert 0.3 < step < 0.7
+    g = json.load(open(os.path.join(ROOT, "profiles", "r05_v61_bench_2ranks_gloo.json")))
+    assert g["n_gpus"] == 2 and g["ranks_seen"] == 2 and g["launched_by"] == "bench.py launch_ranks" and g["training_round"]["replicas_identical"]
