@@ -260,7 +260,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * bgamd_env_kernel_times returns accumulated milliseconds and launch counts since the last call
  * (synchronises).  slots: 0 ordered enumerate, 1 value net, 2 apply, 3 random step,
  * 4 roots+expand (plies 1-3), 5 leaf stage, 6 root term of the incremental value net when it is a launch of its own (the first step of a run; every step of an env
- * below 24 576 lanes or with BGAMD_ROOT_IN_BOUNDARY=0 -- otherwise it runs inside the boundary launch, slot 2; BGAMD_OVERLAP=1 forks the launch onto the env's
+ * below 24 576 lanes (experimental build: or with BGAMD_ROOT_IN_BOUNDARY=0) -- otherwise it runs inside the boundary launch, slot 2; the experimental build's BGAMD_OVERLAP=1 forks the launch onto the env's
  * second stream beside the doubles plies, rounds 1-3's default).  enable: 0 = off, 1 = every group, (mask << 8) | (stride << 20) = only the groups
  * whose bit is set in mask, on every stride-th launch of a group (0 = every launch; an event pair costs ~4 us of
  * stream time, so a timed run samples). */
@@ -271,7 +271,7 @@ int bgamd_evaluate_incremental(bgamd_env *env, int slot, const int32_t *d_root_s
  * root_hidden_resident_kernel, 2 root_hidden_bf16x3_kernel, 3 eval_rows_f32_kernel<root>, 4 no launch of its own: it ran inside the
  * boundary launch of the step before (boundary_kernel<true>, every step of a run but the first); h_out[2]: bit 0 = root pass on the env's
  * second stream, bit 1 = the expansion below the roots (doubles plies 2-3 + leaf stage) ran as ONE launch (expand_all_kernel; the default,
- * BGAMD_EXPAND_MERGED=0 brings doubles_kernel + expand_kernel<LEAF> back); h_out[3]: 1 = experimental build.  bench.py labels its kernels
+ * the experimental build's BGAMD_EXPAND_MERGED=0 brings doubles_kernel + expand_kernel<LEAF> back); h_out[3]: 1 = experimental build.  bench.py labels its kernels
  * from this, not from the environment. */
 const char *bgamd_build_flags(void);
 int bgamd_env_kernel_choice(bgamd_env *env, int32_t h_out[4]);

@@ -262,3 +262,4 @@ def test_weights_outside_the_f16_split_are_refused_at_load(bg, weights):
     a.run_greedy(30)
     b.run_greedy(30)
     assert torch.equal(a.states(), b.states()) and torch.equal(a.turns(), b.turns())
+
