@@ -50,11 +50,11 @@ def test_round5_evidence_is_consistent():
     sum within 5 % of the step period; the occupancy file reproduces from its counter summary; the step-level figure is the duration-
     weighted mean of the three launches."""
     import re
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_v61_bench_f32.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_v62_bench_f32.json")))
     r = d["roofline"]
     assert r["bound"] == "valu" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["ranks_seen"] == 1 and d["training_round"]["replicas_identical"] and "error" not in d["training_round"]
-    txt = open(os.path.join(ROOT, "profiles", "r05_v61_kernel_trace_by_mode.txt")).read()
+    txt = open(os.path.join(ROOT, "profiles", "r05_v62_kernel_trace_by_mode.txt")).read()
     timed = txt[txt.index("the TIMED REGION"):]
     avg = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+calls\s+\d+\s+mean\s+([\d.]+) us", timed, re.M)}
     assert abs(avg["eval_rows_delta_kernel"] * 1e-3 - r["avg_ms"]) < 0.1 * r["avg_ms"]
@@ -65,5 +65,5 @@ def test_round5_evidence_is_consistent():
     parts = [occ[k] for k in ("expand_all_kernel", "eval_rows_delta_kernel", "boundary_kernel<true>")]
     step = sum(x["duration_us"] * x["valu_issue_occupancy"] for x in parts) / sum(x["duration_us"] for x in parts)
     assert 0.3 < step < 0.7
-    g = json.load(open(os.path.join(ROOT, "profiles", "r05_v61_bench_2ranks_gloo.json")))
+    g = json.load(open(os.path.join(ROOT, "profiles", "r05_v62_bench_2ranks_gloo.json")))
     assert g["n_gpus"] == 2 and g["ranks_seen"] == 2 and g["launched_by"] == "bench.py launch_ranks" and g["training_round"]["replicas_identical"]
