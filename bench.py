@@ -269,7 +269,7 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl", rehearsal=Fals
     through torch.distributed with the gloo rehearsal backend (ranks sharing a GPU cannot form an RCCL communicator) -- and the replicas'
     weights are compared bit for bit at the end of every phase (MIN == MAX of a 64-bit checksum over the ranks).  Times are the MAX over
     the ranks between barriers, turns and updates the SUM: round_turns_per_s is the whole job's.
-    rehearsal (ranks SHARING a GPU over gloo): the same route once through -- one pass per replay, three windows per loop -- because processes that
+    rehearsal (ranks SHARING a GPU over gloo): the same route once through -- one pass per replay, two windows per loop -- because processes that
     share a GPU take turns on it: an all-reduce of a device tensor then costs a scheduling quantum (1 ms with two processes on the card, ~35 ms with
     three), and the numbers measure that, not the learner."""
     from backgammon_env.learner import ContinuousSelfPlay, DeviceTDLambdaLearner, play_round
@@ -321,7 +321,7 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl", rehearsal=Fals
         return reduce(cs, dist.ReduceOp.MIN if multi else None) == reduce(cs, dist.ReduceOp.MAX if multi else None), cs
 
     L = learner(games)
-    passes, n_win, first_win = (1, 3, 1) if rehearsal else (2, 8, 4)
+    passes, n_win, first_win = (1, 2, 1) if rehearsal else (2, 8, 4)
     for _ in range(passes):
         (rows, lengths, won), dt_play = timed(lambda: play_round(env, max_plies=600, epsilon=0.05))
     turns = reduce(int(lengths.sum().item()), dist.ReduceOp.SUM if multi else None)
@@ -389,7 +389,7 @@ def training_round(bg, games, w, rank=0, world=1, backend="nccl", rehearsal=Fals
                         ("" if not multi else ", one per training step")
     out["collective_note"] = coll["note"]
     if rehearsal:
-        out["rehearsal"] = "ranks share a GPU: one pass per replay, three windows per loop; times are scheduling quanta, not the learner's"
+        out["rehearsal"] = "ranks share a GPU: one pass per replay, two windows per loop; times are scheduling quanta, not the learner's"
     del L, env
     return out
 

@@ -46,7 +46,7 @@ def test_bench_started_plainly_with_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.time()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--games", "32768",
-                          "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=900, env=env)
+                          "--steps", "20", "--warmup", "5", "--training-round-timeout", "600"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
