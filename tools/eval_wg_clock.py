@@ -24,7 +24,8 @@ for rep in range(5):
     torch.cuda.synchronize()
     x = xv.cpu().numpy()[::-1]                          # x[k] = values[cap - 1 - k]
     xt, xr = x[1024:1536], x[2048:2560]                 # expand_all_kernel: run time and rows of workgroup 0 .. 511 (the first 256: doubles turns)
-    for name, sl in (("doubles workgroups", slice(0, 256)), ("non-doubles workgroups", slice(256, 512))):
+    ND = 316                                                # doubles workgroups of a 65 536-lane launch (62 % of 512, a multiple of the four list parts)
+    for name, sl in (("doubles workgroups", slice(0, ND)), ("non-doubles workgroups", slice(ND, 512))):
         t, r = xt[sl], xr[sl]
         print("   expand_all %s: run time us min %.1f mean %.1f max %.1f sigma %.2f; rows per workgroup min %d mean %.0f max %d; corr(time, rows) %.2f"
               % (name, t.min(), t.mean(), t.max(), t.std(), r.min(), r.mean(), r.max(), np.corrcoef(t, r)[0, 1]), flush=True)
@@ -32,7 +33,7 @@ for rep in range(5):
     _capi.check(env._lib.bgamd_env_unique_rows_read(env._h, cap - 4096 - 4096, 4096, None, C.c_void_p(pv.data_ptr()), None), "read")
     torch.cuda.synchronize()
     pp = pv.cpu().numpy()[::-1].reshape(512, 8)[:, :4]          # pp[b][k] = values[cap - 1 - 4096 - 8 b - k]: node logic, scan, allocation, successors
-    for name, sl in (("doubles", slice(0, 256)), ("non-doubles", slice(256, 512))):
+    for name, sl in (("doubles", slice(0, ND)), ("non-doubles", slice(ND, 512))):
         m = pp[sl].mean(0)
         print("   expand_all %s workgroups, thread 0's time per stage (us, summed over the phases): node logic %.1f  scan + table %.1f  allocation %.1f  successors %.1f  (sum %.1f)"
               % (name, m[0], m[1], m[2], m[3], m.sum()), flush=True)
