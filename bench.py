@@ -665,17 +665,19 @@ def main(argv=None):
     tr = None
     if a.training_round and a.games >= 4096:
         finished = threading.Event()
+        line_lock = threading.Lock()                            # the watchdog and the main thread never both decide to print
 
         def give_up():
-            if finished.is_set():
-                return
-            msg = f"training round did not finish within {a.training_round_timeout:.0f} s on rank {rank}: abandoned (the timed region above is complete)"
-            sys.stderr.write("bench.py: " + msg + "\n")
-            sys.stderr.flush()
-            if rank == 0:
-                out["training_round"] = {"error": msg}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            with line_lock:
+                if finished.is_set():
+                    return
+                msg = f"training round did not finish within {a.training_round_timeout:.0f} s on rank {rank}: abandoned (the timed region above is complete)"
+                sys.stderr.write("bench.py: " + msg + "\n")
+                sys.stderr.flush()
+                if rank == 0:
+                    out["training_round"] = {"error": msg}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
         dog = threading.Timer(a.training_round_timeout, give_up)
         dog.daemon = True
         dog.start()
@@ -691,7 +693,8 @@ def main(argv=None):
             tr = {"error": repr(e)[:300]}
         if use_dist and "error" not in tr:
             dist.barrier()                                      # under the watchdog too: every rank is out of the round
-        finished.set()
+        with line_lock:
+            finished.set()
         dog.cancel()
     tr_failed = tr is not None and "error" in tr                # (the process group may be gone with the rank that failed: no more collectives)
 
